@@ -1,0 +1,227 @@
+"""ctypes front end of the CPU oracle (oracle/kmcf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VACANCY, OXYGEN_DEFECT = 2, 1
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libkmcf_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libkmcf_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_partition.argtypes = [C.c_int, C.c_int, _ip, _ip]
+        L.orc_pattern_brute.restype = C.c_int64
+        L.orc_pattern_cells.restype = C.c_int64
+        for f in (L.orc_pattern_brute, L.orc_pattern_cells):
+            f.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                          _ip, C.c_void_p]
+        L.orc_neighbor_list.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _ip]
+        L.orc_update_charge.argtypes = [_ip, _ip, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int]
+        L.orc_assemble_K.argtypes = [_ip, _ip, _ip, C.c_int, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, C.c_int, _ip, _ip, _dp,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip,
+                                     _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp]
+        L.orc_spmv.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L.orc_spmv_omp.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L.orc_pcg_jacobi.restype = C.c_int
+        L.orc_pcg_jacobi.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int,
+                                     C.c_int, _ip, _ip, C.POINTER(C.c_double), C.c_void_p]
+        L.orc_pcg_jacobi_omp.restype = C.c_int
+        L.orc_pcg_jacobi_omp.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double)]
+        L.orc_omp_threads.restype = C.c_int
+        L.orc_halo_lists.restype = C.c_int
+        L.orc_halo_lists.argtypes = [_ip, _ip, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, C.c_void_p, C.c_void_p]
+        L.orc_update_temperature_global.restype = C.c_double
+        L.orc_update_temperature_global.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                    C.c_double, C.c_double, C.c_double]
+        L.orc_sum_AB_into_A.argtypes = [_dp, _dp, C.c_int]
+        L.orc_poisson_gridless.argtypes = [_dp, _dp, _dp, C.c_int, _ip, C.c_double, C.c_double, C.c_double,
+                                           C.c_int, C.c_int, _dp]
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def partition(n, P):
+    counts = np.zeros(P, np.int32)
+    displs = np.zeros(P, np.int32)
+    lib().orc_partition(n, P, counts, displs)
+    return counts, displs
+
+
+def pattern(x, y, z, lattice, pbc, cutoff, size_i, size_j, start_i, start_j, brute=False):
+    """CSR pattern (row_ptr, col) of one row-block x column-block (block-local columns)."""
+    x, y, z, lattice = _f(x), _f(y), _f(z), _f(lattice)
+    fn = lib().orc_pattern_brute if brute else lib().orc_pattern_cells
+    row_ptr = np.zeros(size_i + 1, np.int32)
+    nnz = fn(x, y, z, lattice, int(pbc), float(cutoff), size_i, size_j, start_i, start_j, row_ptr, None)
+    col = np.zeros(max(int(nnz), 1), np.int32)
+    fn(x, y, z, lattice, int(pbc), float(cutoff), size_i, size_j, start_i, start_j, row_ptr,
+       col.ctypes.data_as(C.c_void_p))
+    return row_ptr, col[:nnz]
+
+
+def neighbor_list(x, y, z, nn_dist=3.5, nn=52, count=None, displ=0):
+    x, y, z = _f(x), _f(y), _f(z)
+    N = len(x)
+    count = N if count is None else count
+    out = np.empty(count * nn, np.int32)
+    lib().orc_neighbor_list(x, y, z, N, float(nn_dist), nn, count, displ, out)
+    return out.reshape(count, nn)
+
+
+def update_charge(element, charge, neigh_idx, metals, row_start=0, row_end=None):
+    element, metals = _i(element), _i(metals)
+    charge = _i(charge).copy()
+    nn = neigh_idx.shape[1]
+    row_end = len(element) if row_end is None else row_end
+    lib().orc_update_charge(element, charge, _i(neigh_idx).reshape(-1), nn, metals, len(metals), row_start, row_end)
+    return charge
+
+
+class KSystem:
+    """Global interface pattern + contact patterns of a device (a3)."""
+
+    def __init__(self, xyz, lattice, pbc, nn_dist, N_left, N_right):
+        x, y, z = _f(xyz[:, 0]), _f(xyz[:, 1]), _f(xyz[:, 2])
+        self.N = len(x)
+        self.N_left, self.N_right = int(N_left), int(N_right)
+        self.n = self.N - self.N_left - self.N_right
+        n = self.n
+        self.row_ptr, self.col = pattern(x, y, z, lattice, pbc, nn_dist, n, n, N_left, N_left)
+        self.left_row_ptr, self.left_col = pattern(x, y, z, lattice, pbc, nn_dist, n, N_left, N_left, 0)
+        self.right_row_ptr, self.right_col = pattern(x, y, z, lattice, pbc, nn_dist, n, N_right, N_left, N_left + n)
+        self.nnz = len(self.col)
+
+
+def assemble_K(ks, element, charge, metals, high_G, low_G, Vd, P=1):
+    """Values + diag/dinv/rhs for all rows, rank by rank with the reference's
+    per-block diagonal summation order.  Returns dict of global arrays."""
+    n = ks.n
+    counts, displs = partition(n, P)
+    val = np.zeros(ks.nnz, np.float64)
+    diag = np.zeros(n)
+    dinv = np.zeros(n)
+    rhs = np.zeros(n)
+    left = np.zeros(n)
+    right = np.zeros(n)
+    element, charge, metals = _i(element), _i(charge), _i(metals)
+    for r in range(P):
+        r0, nr = int(displs[r]), int(counts[r])
+        lrp = _i(ks.left_row_ptr[r0:r0 + nr + 1] - ks.left_row_ptr[r0])
+        lc = _i(ks.left_col[ks.left_row_ptr[r0]:ks.left_row_ptr[r0 + nr]])
+        rrp = _i(ks.right_row_ptr[r0:r0 + nr + 1] - ks.right_row_ptr[r0])
+        rc = _i(ks.right_col[ks.right_row_ptr[r0]:ks.right_row_ptr[r0 + nr]])
+        if len(lc) == 0:
+            lc = np.zeros(1, np.int32)
+        if len(rc) == 0:
+            rc = np.zeros(1, np.int32)
+        d, di, rh, le, ri = (np.zeros(max(nr, 1)) for _ in range(5))
+        lib().orc_assemble_K(element, charge, metals, len(metals), high_G, low_G, Vd,
+                             ks.N_left, n, ks.row_ptr, ks.col, val,
+                             r0, nr, P, r, counts, displs, lrp, lc, rrp, rc, d, di, rh, le, ri)
+        diag[r0:r0 + nr], dinv[r0:r0 + nr], rhs[r0:r0 + nr] = d[:nr], di[:nr], rh[:nr]
+        left[r0:r0 + nr], right[r0:r0 + nr] = le[:nr], ri[:nr]
+    return dict(val=val, diag=diag, dinv=dinv, rhs=rhs, left=left, right=right)
+
+
+def spmv(row_ptr, col, val, x, omp=False):
+    n = len(row_ptr) - 1
+    y = np.zeros(n)
+    (lib().orc_spmv_omp if omp else lib().orc_spmv)(n, _i(row_ptr), _i(col), _f(val), _f(x), y)
+    return y
+
+
+def pcg_jacobi(row_ptr, col, val, rhs, x0, dinv, tol, max_it, P=1, fixed_iters=0, history=False):
+    """Returns (x, iters, relres[, rz_hist]); rhs/x0 are not modified."""
+    n = len(row_ptr) - 1
+    counts, displs = partition(n, P)
+    r = _f(rhs).copy()
+    x = _f(x0).copy()
+    rel = C.c_double(0.0)
+    hist = np.zeros(max_it + 2 + fixed_iters) if history else None
+    it = lib().orc_pcg_jacobi(n, _i(row_ptr), _i(col), _f(val), r, x, _f(dinv), float(tol), int(max_it),
+                              int(fixed_iters), P, counts, displs, C.byref(rel),
+                              hist.ctypes.data_as(C.c_void_p) if history else None)
+    if history:
+        return x, it, rel.value, hist[:it + 1]
+    return x, it, rel.value
+
+
+def pcg_jacobi_omp(row_ptr, col, val, rhs, x0, dinv, tol, max_it, fixed_iters=0):
+    n = len(row_ptr) - 1
+    r = _f(rhs).copy()
+    x = _f(x0).copy()
+    rel = C.c_double(0.0)
+    it = lib().orc_pcg_jacobi_omp(n, _i(row_ptr), _i(col), _f(val), r, x, _f(dinv), float(tol), int(max_it),
+                                  int(fixed_iters), C.byref(rel))
+    return x, it, rel.value
+
+
+def omp_threads():
+    return lib().orc_omp_threads()
+
+
+def halo_lists(row_ptr, col, P, rank):
+    """Neighbour list + halo index lists of `rank` (dist_matrix.cpp:237-487)."""
+    n = len(row_ptr) - 1
+    counts, displs = partition(n, P)
+    nb = np.zeros(P, np.int32)
+    nnzb = np.zeros(P, np.int32)
+    nc = np.zeros(P, np.int32)
+    nr = np.zeros(P, np.int32)
+    nnb = lib().orc_halo_lists(_i(row_ptr), _i(col), P, rank, counts, displs, nb, nnzb, nc, nr, None, None)
+    cols = np.zeros(max(int(nc[:nnb].sum()), 1), np.int32)
+    rows = np.zeros(max(int(nr[:nnb].sum()), 1), np.int32)
+    lib().orc_halo_lists(_i(row_ptr), _i(col), P, rank, counts, displs, nb, nnzb, nc, nr,
+                         cols.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p))
+    out = []
+    co = ro = 0
+    for k in range(nnb):
+        out.append(dict(rank=int(nb[k]), nnz=int(nnzb[k]),
+                        cols=cols[co:co + nc[k]].copy(), rows=rows[ro:ro + nr[k]].copy()))
+        co += nc[k]
+        ro += nr[k]
+    return out
+
+
+def update_temperature_global(site_power, T_bg, a, b, number_steps, C_thermal, small_step):
+    return lib().orc_update_temperature_global(_f(site_power), len(site_power), T_bg, a, b, number_steps,
+                                               C_thermal, small_step)
+
+
+def poisson_gridless(xyz, charge, sigma, k, cutoff=20.0, count=None, displ=0):
+    x, y, z = _f(xyz[:, 0]), _f(xyz[:, 1]), _f(xyz[:, 2])
+    N = len(x)
+    count = N if count is None else count
+    pot = np.zeros(N)
+    lib().orc_poisson_gridless(x, y, z, N, _i(charge), sigma, k, cutoff, count, displ, pot)
+    return pot

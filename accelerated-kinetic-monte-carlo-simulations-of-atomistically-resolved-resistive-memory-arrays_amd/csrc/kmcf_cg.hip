@@ -1,0 +1,365 @@
+// Jacobi-preconditioned CG for gfx950, replacing
+// iterative_solver::conjugate_gradient_jacobi / conjugate_gradient
+// (dist_iterative/dist_conjugate_gradient.cpp:17-121, 149-276).
+//
+// Same recurrence, same operation order and same stopping rule as the reference
+// (r.z/(b.b) > tol^2 && k <= max_it, :217), but:
+//  * the reference's 6 hipBLAS calls + 1 Hadamard kernel + 2 host-returning dots
+//    per iteration become 3 kernels (p update | SpMV + p.Ap | x,r,z update + r.z);
+//  * alpha, beta, r.z, p.Ap and the convergence flag live in device memory; the
+//    host enqueues KMCF_CHUNK_ITERS iterations at a time and reads the flag back
+//    once per chunk.  Kernels launched after convergence return at once, so x is
+//    exactly the iterate the reference would have stopped at;
+//  * dot products: one partial per block, summed in a fixed order by every block of
+//    the consuming kernel (bitwise reproducible, no fp64 atomics).  With several
+//    ranks a 1-block finalize + ncclAllReduce on the compute stream sits in between.
+//
+// HBM traffic per iteration besides the SpMV: p update 3R+1W, x/r update 5R+2W
+// vector passes = 88 B/row (the reference's op sequence: 144 B/row).
+#include <cmath>
+
+#include "kmcf_internal.hpp"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *lds4)
+{
+    v = wave_sum64(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds4[w] = v;
+    __syncthreads();
+    double t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    __syncthreads();
+    return t;
+}
+
+// Sum of two partial arrays in a fixed order; every thread of the block gets the result.
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ a, int na,
+                                                  const double *__restrict__ b, int nb, double *lds4)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < na; i += KMCF_BLOCK) v += a[i];
+    for (int i = threadIdx.x; i < nb; i += KMCF_BLOCK) v += b[i];
+    return block_sum(v, lds4);
+}
+
+struct part_ref {
+    const double *a;
+    int na;
+    const double *b;
+    int nb;
+};
+
+// r = b - A x0 ; z = r .* dinv ; partial r.z and b.b   (dist_conjugate_gradient.cpp:187, 201-212)
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_init_kernel(int n, double *__restrict__ r, const double *__restrict__ Ap,
+                                                             const double *__restrict__ dinv,
+                                                             double *__restrict__ part_rz, double *__restrict__ part_bb)
+{
+    __shared__ double lds4[4];
+    double rz = 0.0, bb = 0.0;
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+        double b = r[i];
+        bb += b * b;
+        double ri = b + (-1.0) * Ap[i];
+        r[i] = ri;
+        double z = PRECOND ? ri * dinv[i] : ri;
+        rz += ri * z;
+    }
+    double t = block_sum(rz, lds4);
+    double u = block_sum(bb, lds4);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = t; part_bb[blockIdx.x] = u; }
+}
+
+// One block: S->red[slot] = sum of partials (input of the all-reduce).
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_finalize_kernel(part_ref p0, int slot0, part_ref p1, int slot1,
+                                                                 kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    double t0 = reduce_partials(p0.a, p0.na, p0.b, p0.nb, lds4);
+    if (threadIdx.x == 0) S->red[slot0] = t0;
+    if (slot1 >= 0) {
+        double t1 = reduce_partials(p1.a, p1.na, p1.b, p1.nb, lds4);
+        if (threadIdx.x == 0) S->red[slot1] = t1;
+    }
+}
+
+// Loop head of iteration k: stopping rule, beta, p = z + beta p   (:217-227)
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restrict__ p, const double *__restrict__ r,
+                                                          const double *__restrict__ dinv, part_ref prz, part_ref pbb,
+                                                          kmcf_scalars *__restrict__ S, int parity, int first,
+                                                          double tol2, int check_tol)
+{
+    __shared__ double lds4[4];
+    if (S->done) return;
+    const double rz_new = reduce_partials(prz.a, prz.na, prz.b, prz.nb, lds4);
+    double bb;
+    if (first) bb = reduce_partials(pbb.a, pbb.na, pbb.b, pbb.nb, lds4);
+    else bb = S->bb;
+    // check_tol: 0 fixed iteration count; 1 relative rule r.z/b.b > tol^2 (:217);
+    // 2 absolute rule of solve_sparse_CG_Jacobi (src/iterative_solvers_gpu.cu:838-840, 858):
+    //   first test on ||r|| (hipblasDnrm2), later ones on ||r||^2 (hipblasDdot)
+    bool go = true;
+    if (check_tol == 1) go = rz_new / bb > tol2;
+    else if (check_tol == 2) go = (first ? sqrt(rz_new) : rz_new) > tol2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->rz_last = rz_new;
+        if (first) S->bb = bb;
+        if (go) { S->rz[parity] = rz_new; S->iters += 1; }
+        else S->done = 1;
+    }
+    if (!go) return;
+    if (first) {
+        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK)
+            p[i] = PRECOND ? r[i] * dinv[i] : r[i];                       // :226 dcopy(z -> p)
+    } else {
+        const double beta = rz_new / S->rz[parity ^ 1];                    // :220
+        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+            double z = PRECOND ? r[i] * dinv[i] : r[i];
+            double bp = beta * p[i];                                       // :221 dscal
+            p[i] = bp + z;                                                 // :222 daxpy
+        }
+    }
+}
+
+// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; z = r .* dinv ; partial r.z   (:243-264)
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__restrict__ x, double *__restrict__ r,
+                                                           const double *__restrict__ p, const double *__restrict__ Ap,
+                                                           const double *__restrict__ dinv, part_ref ppap,
+                                                           kmcf_scalars *__restrict__ S, int parity,
+                                                           double *__restrict__ part_rz)
+{
+    __shared__ double lds4[4];
+    if (S->done) return;
+    const double pAp = reduce_partials(ppap.a, ppap.na, ppap.b, ppap.nb, lds4);
+    const double a = S->rz[parity] / pAp;
+    const double na = -a;
+    double rz = 0.0;
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+        x[i] = x[i] + a * p[i];
+        double ri = r[i] + na * Ap[i];
+        r[i] = ri;
+        double z = PRECOND ? ri * dinv[i] : ri;
+        rz += ri * z;
+    }
+    double t = block_sum(rz, lds4);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t;
+        if (blockIdx.x == 0) S->pAp = pAp;
+    }
+}
+
+// After the loop: the r.z the reference prints (:273) if the loop did not end on the stopping rule.
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_tail_kernel(part_ref prz, kmcf_scalars *__restrict__ S)
+{
+    __shared__ double lds4[4];
+    if (S->done) return;
+    double t = reduce_partials(prz.a, prz.na, prz.b, prz.nb, lds4);
+    if (threadIdx.x == 0) S->rz_last = t;
+}
+
+int vec_grid(int n)
+{
+    int64_t g = ((int64_t)n + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return (int)g;
+}
+
+template <bool PRECOND>
+int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolute, kmcf_solve_stats_t *stats)
+{
+    kmcf_comm *c = m->comm;
+    hipStream_t st = c->stream;
+    const int n = m->n_loc;
+    const int vg = vec_grid(n);
+    const bool multi = c->nranks > 1;
+    kmcf_scalars *S = m->d_S;
+    const double tol2 = tol * tol;
+    const int check_tol = fixed_iters > 0 ? 0 : (absolute ? 2 : 1);
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+
+    // partial sources: local partial arrays, or the all-reduced scalar in S->red
+    part_ref prz_loc{m->d_part_b, vg, nullptr, 0};
+    part_ref pbb_loc{m->d_part_c, vg, nullptr, 0};
+    part_ref ppap_loc{m->d_part_a, m->spmv_grid, m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
+    part_ref prz = multi ? part_ref{&S->red[0], 1, nullptr, 0} : prz_loc;
+    part_ref pbb = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pbb_loc;
+    part_ref ppap = multi ? part_ref{&S->red[2], 1, nullptr, 0} : ppap_loc;
+
+    KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
+    KMCF_HIP(hipEventRecord(c->ev_t0, st));
+    // p <- x0 ; Ap = A x0 ; r = b - Ap ; z ; r.z ; b.b    (:178-213)
+    KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    KMCF_TRY(kmcf_spmv_device(m, false, false));
+    cg_init_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, m->d_part_b, m->d_part_c);
+    KMCF_HIP(hipGetLastError());
+    if (multi) {
+        cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz_loc, 0, pbb_loc, 1, S, 0);
+        KMCF_HIP(hipGetLastError());
+        KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 2));
+    }
+
+    int launched = 0;
+    bool done = false;
+    while (launched < limit && !done) {
+        int chunk = limit - launched;
+        if (chunk > KMCF_CHUNK_ITERS) chunk = KMCF_CHUNK_ITERS;
+        for (int i = 0; i < chunk; ++i) {
+            const int k = launched + i + 1;  // reference's k
+            const int parity = k & 1;
+            cg_p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_p, m->d_r, m->d_dinv, prz, pbb, S, parity,
+                                                            k == 1 ? 1 : 0, tol2, check_tol);
+            KMCF_HIP(hipGetLastError());
+            KMCF_TRY(kmcf_spmv_device(m, true, true));
+            if (multi) {
+                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(ppap_loc, 2, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+                KMCF_HIP(hipGetLastError());
+                KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[2], 1));
+            }
+            cg_xr_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_p, m->d_Ap, m->d_dinv, ppap, S,
+                                                             parity, m->d_part_b);
+            KMCF_HIP(hipGetLastError());
+            if (multi) {
+                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz_loc, 0, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+                KMCF_HIP(hipGetLastError());
+                KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 1));
+            }
+        }
+        launched += chunk;
+        if (check_tol) {
+            KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            KMCF_HIP(hipStreamSynchronize(st));
+            done = c->h_pinned[0] != 0;
+        }
+    }
+    // the loop condition is evaluated once more after the last iteration (:217): it
+    // decides `converged` and provides the printed residual (:273)
+    if (!done) {
+        cg_tail_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz, S);
+        KMCF_HIP(hipGetLastError());
+    }
+    KMCF_HIP(hipEventRecord(c->ev_t1, st));
+    kmcf_scalars hS;
+    KMCF_HIP(hipMemcpyAsync(&hS, S, sizeof(hS), hipMemcpyDeviceToHost, st));
+    KMCF_HIP(hipStreamSynchronize(st));
+    if (multi) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    if (stats) {
+        stats->iterations = hS.iters;
+        stats->bb = hS.bb;
+        stats->rz = hS.rz_last;
+        stats->relres = std::sqrt(hS.rz_last / hS.bb);
+        stats->converged = (hS.done != 0) || !((absolute ? hS.rz_last : hS.rz_last / hS.bb) > tol2);
+        float ms = 0.f;
+        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        stats->ms_solve = ms;
+    }
+    return KMCF_OK;
+}
+
+}  // namespace
+
+// Solve on the matrix workspace: m->d_r holds b, m->d_x the start guess, m->d_dinv 1/diag.
+int kmcf_pcg_workspace(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
+{
+    if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats);
+    return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats);
+}
+
+namespace {
+
+// computeDiagonalInvSqrt, src/iterative_solvers_gpu.cu:630-652
+__global__ __launch_bounds__(KMCF_BLOCK) void diag_inv_sqrt_kernel(int n, const int *__restrict__ row_ptr,
+                                                                   const int *__restrict__ col, const double *__restrict__ val,
+                                                                   double *__restrict__ dis)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double d = 0.0;
+        for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j)
+            if (col[j] == i) { d = val[j]; break; }
+        dis[i] = 1.0 / sqrt(d);
+    }
+}
+
+// jacobi_precondition_matrix, :666-680 (16 lanes per row here)
+__global__ __launch_bounds__(KMCF_BLOCK) void scale_matrix_kernel(int n, const int *__restrict__ row_ptr,
+                                                                  const int *__restrict__ col, double *__restrict__ val,
+                                                                  const double *__restrict__ dis)
+{
+    constexpr int LPR = 16, RPB = KMCF_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    for (int r = blockIdx.x * RPB + threadIdx.x / LPR; r < n; r += gridDim.x * RPB)
+        for (int j = row_ptr[r] + lane; j < row_ptr[r + 1]; j += LPR) val[j] = val[j] * dis[r] * dis[col[j]];
+}
+
+// jacobi_precondition_array :654-664 (mode 0) / jacobi_unprecondition_array :682-692 (mode 1)
+__global__ __launch_bounds__(KMCF_BLOCK) void scale_vector_kernel(int n, double *__restrict__ a, const double *__restrict__ dis, int mode)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        a[i] = mode ? a[i] * 1 / dis[i] : a[i] * dis[i];
+}
+
+}  // namespace
+
+extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double *d_x, double tol, int max_iterations,
+                                           kmcf_solve_stats_t *stats)
+{
+    KMCF_CHECK(m && d_rhs && d_x, KMCF_ERR_ARG, "kmcf_solve_sparse_CG_Jacobi: null argument");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_solve_sparse_CG_Jacobi: host-only matrix");
+    KMCF_CHECK(m->comm->nranks == 1, KMCF_ERR_ARG, "kmcf_solve_sparse_CG_Jacobi: single-rank solver (reference: one GPU)");
+    kmcf_comm *c = m->comm;
+    KMCF_HIP(hipSetDevice(c->device));
+    const int n = m->n_loc;
+    const size_t bytes = (size_t)n * sizeof(double);
+    const int g = vec_grid(n);
+    double *dis = m->d_dinv;  // workspace: 1/sqrt(diag)
+    diag_inv_sqrt_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_rhs, dis, 0);       // rhs scaled in place (:740)
+    scale_matrix_kernel<<<g * 4, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);  // :745
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_x, dis, 1);         // start guess (:751)
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipMemcpyAsync(m->d_r, d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipMemcpyAsync(m->d_x, d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
+    // the same iterates as r = b - A y, p = r used here
+    KMCF_TRY((pcg_loop<false>(m, std::sqrt(tol * tol), max_iterations, 0, 1, stats)));
+    KMCF_HIP(hipMemcpyAsync(d_x, m->d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    // pcg_loop<false> reuses d_dinv? no: the unpreconditioned loop never reads it, so `dis` is intact
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_x, dis, 0);         // y = D^-1/2 y' (:864)
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const double *d_diag_inv,
+                               double relative_tolerance, int max_iterations, int fixed_iters,
+                               kmcf_solve_stats_t *stats)
+{
+    KMCF_CHECK(m && d_r && d_x, KMCF_ERR_ARG, "kmcf_pcg_jacobi: null argument");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_pcg_jacobi: host-only matrix");
+    KMCF_CHECK(max_iterations >= 0 && fixed_iters >= 0, KMCF_ERR_ARG, "kmcf_pcg_jacobi: negative iteration count");
+    kmcf_comm *c = m->comm;
+    KMCF_CHECK(c->connected, KMCF_ERR_COMM, "kmcf_pcg_jacobi: communicator not connected");
+    KMCF_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)m->n_loc * sizeof(double);
+    // the caller's vectors may be unaligned slices (x is gpubuf.site_potential_boundary +
+    // N_left + disp, src/potential_solver_gpu.cu:861): work on the aligned workspace
+    KMCF_HIP(hipMemcpyAsync(m->d_r, d_r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipMemcpyAsync(m->d_x, d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (d_diag_inv) KMCF_HIP(hipMemcpyAsync(m->d_dinv, d_diag_inv, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_TRY(kmcf_pcg_workspace(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats));
+    KMCF_HIP(hipMemcpyAsync(d_r, m->d_r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipMemcpyAsync(d_x, m->d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipStreamSynchronize(c->stream));   // results visible on return (:271 hipDeviceSynchronize)
+    return KMCF_OK;
+}

@@ -1,0 +1,244 @@
+// Communicator: one rank (= one process = one GPU) of the solver group.
+// Replaces the reference's MPI usage on the hot path:
+//   MPI_Allreduce of the CG dots      -> ncclAllReduce on device scalars, compute stream
+//   MPI_Isend/Irecv of packed halos   -> grouped ncclSend/ncclRecv on the comm stream,
+//                                        receiving straight into the compact halo slots
+//   MPI_Gatherv/Bcast/Allgatherv      -> grouped ncclBroadcast (uneven counts)
+// RCCL is resolved with dlopen at connect time so that 1-rank use needs no RCCL.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "kmcf_internal.hpp"
+
+namespace {
+
+thread_local char g_err[1024] = "";
+
+struct rccl_api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+rccl_api g_rccl;
+std::mutex g_rccl_mu;
+
+int load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return KMCF_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    KMCF_CHECK(h != nullptr, KMCF_ERR_COMM, "cannot dlopen librccl.so.1: %s", dlerror());
+#define KMCF_SYM(field, name)                                                     \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));      \
+    KMCF_CHECK(g_rccl.field != nullptr, KMCF_ERR_COMM, "librccl lacks %s", name)
+    KMCF_SYM(GetUniqueId, "ncclGetUniqueId");
+    KMCF_SYM(CommInitRank, "ncclCommInitRank");
+    KMCF_SYM(CommDestroy, "ncclCommDestroy");
+    KMCF_SYM(AllReduce, "ncclAllReduce");
+    KMCF_SYM(Broadcast, "ncclBroadcast");
+    KMCF_SYM(Send, "ncclSend");
+    KMCF_SYM(Recv, "ncclRecv");
+    KMCF_SYM(GroupStart, "ncclGroupStart");
+    KMCF_SYM(GroupEnd, "ncclGroupEnd");
+    KMCF_SYM(GetErrorString, "ncclGetErrorString");
+#undef KMCF_SYM
+    g_rccl.handle = h;
+    return KMCF_OK;
+}
+
+#define KMCF_NCCL(call)                                                                      \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) {                                                             \
+            kmcf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+            return KMCF_ERR_COMM;                                                            \
+        }                                                                                    \
+    } while (0)
+
+}  // namespace
+
+void kmcf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *kmcf_last_error(void) { return g_err; }
+extern "C" int kmcf_version(void) { return 100; }
+
+extern "C" int kmcf_partition(int nrows, int nranks, int *h_counts, int *h_displs)
+{
+    // src/KMC_comm.h:249-263
+    KMCF_CHECK(nrows >= 0 && nranks > 0 && h_counts && h_displs, KMCF_ERR_ARG, "kmcf_partition: bad arguments");
+    int per = nrows / nranks;
+    for (int i = 0; i < nranks; ++i) h_counts[i] = (i < nrows % nranks) ? per + 1 : per;
+    h_displs[0] = 0;
+    for (int i = 1; i < nranks; ++i) h_displs[i] = h_displs[i - 1] + h_counts[i - 1];
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int rank)
+{
+    KMCF_CHECK(out && nranks >= 1 && rank >= 0 && rank < nranks, KMCF_ERR_ARG, "kmcf_comm_create: bad rank/nranks");
+    if (device < 0) {
+        // host-only planning communicator: partition / halo-list logic without a GPU;
+        // every compute entry point refuses it (KMCF_ERR_STATE)
+        kmcf_comm *c = new kmcf_comm();
+        c->device = -1;
+        c->nranks = nranks;
+        c->rank = rank;
+        c->connected = false;
+        *out = c;
+        return KMCF_OK;
+    }
+    int ndev = 0;
+    KMCF_HIP(hipGetDeviceCount(&ndev));
+    KMCF_CHECK(device >= 0 && device < ndev, KMCF_ERR_ARG, "kmcf_comm_create: device %d of %d", device, ndev);
+    KMCF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    KMCF_HIP(hipGetDeviceProperties(&prop, device));
+    KMCF_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0, KMCF_ERR_HIP,
+               "libkmcfield is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+    kmcf_comm *c = new kmcf_comm();
+    c->device = device;
+    c->nranks = nranks;
+    c->rank = rank;
+    KMCF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    KMCF_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    KMCF_HIP(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    KMCF_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    KMCF_HIP(hipEventCreate(&c->ev_t0));
+    KMCF_HIP(hipEventCreate(&c->ev_t1));
+    KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 16 * sizeof(int), hipHostMallocDefault));
+    c->connected = (nranks == 1);
+    *out = c;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_comm_unique_id(void *h_id128)
+{
+    KMCF_CHECK(h_id128, KMCF_ERR_ARG, "kmcf_comm_unique_id: null buffer");
+    KMCF_TRY(load_rccl());
+    static_assert(sizeof(ncclUniqueId) == KMCF_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    KMCF_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(h_id128, &id, sizeof(id));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
+{
+    KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_connect: null comm");
+    if (c->nranks == 1) { c->connected = true; return KMCF_OK; }
+    KMCF_CHECK(h_id128, KMCF_ERR_ARG, "kmcf_comm_connect: null id");
+    KMCF_TRY(load_rccl());
+    KMCF_HIP(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, h_id128, sizeof(id));
+    ncclComm_t comm;
+    KMCF_NCCL(g_rccl.CommInitRank(&comm, c->nranks, id, c->rank));
+    c->nccl = comm;
+    c->connected = true;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_comm_destroy(kmcf_comm *c)
+{
+    if (!c) return KMCF_OK;
+    if (c->device < 0) { delete c; return KMCF_OK; }
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    if (c->nccl) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
+    if (c->ev_packed) hipEventDestroy(c->ev_packed);
+    if (c->ev_halo) hipEventDestroy(c->ev_halo);
+    if (c->ev_t0) hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) hipEventDestroy(c->ev_t1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    delete c;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_comm_sync(kmcf_comm *c)
+{
+    KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_sync: null comm");
+    if (c->device < 0) return KMCF_OK;
+    KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    return KMCF_OK;
+}
+
+extern "C" void *kmcf_comm_stream(kmcf_comm *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+// Sum `count` doubles in place over all ranks, on the compute stream, device resident.
+int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
+{
+    if (c->nranks == 1) return KMCF_OK;
+    KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
+    KMCF_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum,
+                               static_cast<ncclComm_t>(c->nccl), c->stream));
+    return KMCF_OK;
+}
+
+// Halo exchange of p on the comm stream: for every neighbour k>=1 send the packed
+// rows_per_neighbour[k] entries and receive nnz_cols_per_neighbour[k] doubles
+// directly into the halo slots of d_p (no unpack kernel: column ids were remapped
+// to compact halo slots at matrix build).
+int kmcf_comm_send_recv_halo(kmcf_matrix *m)
+{
+    kmcf_comm *c = m->comm;
+    if (m->number_of_neighbours <= 1) return KMCF_OK;
+    KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
+    ncclComm_t comm = static_cast<ncclComm_t>(c->nccl);
+    KMCF_NCCL(g_rccl.GroupStart());
+    for (int k = 1; k < m->number_of_neighbours; ++k) {
+        int peer = m->neighbours[k];
+        size_t ns = m->rows_per_neighbour[k].size();
+        size_t nr = m->cols_per_neighbour[k].size();
+        if (ns) KMCF_NCCL(g_rccl.Send(m->d_send_buf + m->send_offset[k], ns, ncclDouble, peer, comm, c->comm_stream));
+        if (nr) KMCF_NCCL(g_rccl.Recv(m->d_p + m->n_loc + m->halo_offset[k], nr, ncclDouble, peer, comm, c->comm_stream));
+    }
+    KMCF_NCCL(g_rccl.GroupEnd());
+    return KMCF_OK;
+}
+
+// In-place all-gather with uneven counts: rank q owns d_buf[displs[q] .. +counts[q]).
+template <typename T>
+static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int *displs, ncclDataType_t dt)
+{
+    if (c->nranks == 1) return KMCF_OK;
+    KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
+    ncclComm_t comm = static_cast<ncclComm_t>(c->nccl);
+    KMCF_NCCL(g_rccl.GroupStart());
+    for (int q = 0; q < c->nranks; ++q)
+        if (counts[q] > 0)
+            KMCF_NCCL(g_rccl.Broadcast(d_buf + displs[q], d_buf + displs[q], (size_t)counts[q], dt, q, comm, c->stream));
+    KMCF_NCCL(g_rccl.GroupEnd());
+    return KMCF_OK;
+}
+
+int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs)
+{
+    return allgatherv_impl<double>(c, d_buf, counts, displs, ncclDouble);
+}
+
+int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs)
+{
+    return allgatherv_impl<int>(c, d_buf, counts, displs, ncclInt32);
+}

@@ -1,0 +1,150 @@
+// Internal declarations of libkmcfield (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "kmcfield.h"
+
+// ---------------------------------------------------------------- errors
+void kmcf_set_error(const char *fmt, ...);
+
+#define KMCF_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            kmcf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return KMCF_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define KMCF_CHECK(cond, code, ...)        \
+    do {                                   \
+        if (!(cond)) {                     \
+            kmcf_set_error(__VA_ARGS__);   \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define KMCF_TRY(call)            \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != KMCF_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------- tuning
+constexpr int KMCF_BLOCK = 256;          // 4 wavefronts
+constexpr int KMCF_MAX_PARTIALS = 2048;  // = 256 CUs x 8 resident blocks
+constexpr int KMCF_CHUNK_ITERS = 32;     // CG iterations enqueued between convergence read-backs
+
+// Device-resident CG scalars (never round-trip through the host inside the loop).
+struct kmcf_scalars {
+    double bb;        // ||b||^2
+    double rz[2];     // r.z ping-pong by iteration parity
+    double rz_last;   // most recent r.z
+    double pAp;
+    double red[4];    // all-reduce staging (multi-rank)
+    int done;         // stopping rule met
+    int iters;        // iterations executed
+    int pad[2];
+};
+
+struct kmcf_comm {
+    int device = 0;
+    int nranks = 1;
+    int rank = 0;
+    hipStream_t stream = nullptr;       // compute stream
+    hipStream_t comm_stream = nullptr;  // halo exchange stream
+    hipEvent_t ev_packed = nullptr;     // compute -> comm
+    hipEvent_t ev_halo = nullptr;       // comm -> compute
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    void *nccl = nullptr;               // ncclComm_t
+    bool connected = false;
+    int *h_pinned = nullptr;            // 16 ints pinned host (done/iters read-back)
+};
+
+struct kmcf_matrix {
+    kmcf_comm *comm = nullptr;
+    int matrix_size = 0;
+    int n_loc = 0;
+    int row0 = 0;                 // displs[rank]
+    int64_t nnz = 0;
+    std::vector<int> counts, displs;
+
+    // neighbour bookkeeping (host) -- mirrors Distributed_matrix
+    int number_of_neighbours = 1;
+    std::vector<int> neighbours;              // [0] = self, cyclic order
+    std::vector<int> nnz_per_neighbour;
+    std::vector<std::vector<int>> cols_per_neighbour;  // block-local columns to receive
+    std::vector<std::vector<int>> rows_per_neighbour;  // local rows to send
+    std::vector<int> halo_offset;             // start of neighbour k's slots in the halo (k>=1)
+    int n_halo = 0;
+    int n_send = 0;
+    std::vector<int> send_offset;
+    int n_boundary_rows = 0;
+
+    // creation-order -> internal nnz position (identity today; kept for set/get_values)
+    // device CSR with compact-halo column ids: [0,n_loc) own, [n_loc, n_loc+n_halo) halo slots
+    int *d_row_ptr = nullptr;
+    int *d_col = nullptr;
+    double *d_val = nullptr;
+    int *d_boundary_rows = nullptr;    // list of local rows touching the halo
+    unsigned char *d_is_boundary = nullptr;  // per-row flag (nullptr if no halo)
+    int *d_send_idx = nullptr;         // concatenated rows_per_neighbour[k>=1]
+    double *d_send_buf = nullptr;
+    int *d_halo_gid = nullptr;         // global column id of each halo slot
+
+    // CG workspace (allocated once; the reference mallocs Ap/z in create_cg_overhead)
+    double *d_p = nullptr;             // n_loc + n_halo   (Distributed_vector)
+    double *d_Ap = nullptr;
+    double *d_r = nullptr;
+    double *d_x = nullptr;
+    double *d_dinv = nullptr;
+    double *d_part_a = nullptr;        // KMCF_MAX_PARTIALS x 2 (pAp partials)
+    double *d_part_b = nullptr;        // rz partials
+    double *d_part_c = nullptr;        // bb partials
+    kmcf_scalars *d_S = nullptr;
+
+    // SpMV launch plan
+    int spmv_grid = 0;                 // interior pass grid (= number of pAp partials it writes)
+    int spmv_grid_b = 0;               // boundary pass grid
+    int spmv_lpr = 16;                 // lanes per row
+};
+
+struct kmcf_kstate {
+    kmcf_comm *comm = nullptr;
+    kmcf_matrix *K = nullptr;
+    int N = 0, N_left = 0, N_right = 0, N_interface = 0;
+    // host copies of the pattern in global interface column ids (for export)
+    std::vector<int> h_row_ptr, h_col;
+    std::vector<int> h_left_row_ptr, h_left_col, h_right_row_ptr, h_right_col;
+    // contact patterns on device (gpubuf.left_row_ptr_d etc.)
+    int *d_left_row_ptr = nullptr, *d_left_col = nullptr;
+    int *d_right_row_ptr = nullptr, *d_right_col = nullptr;
+    int *d_diag_pos = nullptr;         // nnz index of the diagonal entry per row
+    unsigned char *d_cls = nullptr;    // per-site class (N): 1 metal, 2 uncharged vacancy, 0 other
+    double *d_diag = nullptr, *d_left = nullptr, *d_right = nullptr, *d_rhs = nullptr;
+    bool assembled = false;
+    // replicated interface solution for sum_and_gather
+    double *d_gather = nullptr;
+};
+
+// ---------------------------------------------------------------- internal entry points
+// spmv.hip
+int kmcf_spmv_plan(kmcf_matrix *m);
+// Ap = A*p on m->d_p (already holding local p), writes m->d_Ap and pAp partials.
+int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done);
+// cg.hip
+int kmcf_halo_exchange_begin(kmcf_matrix *m);   // pack + send/recv on the comm stream
+int kmcf_halo_exchange_end(kmcf_matrix *m);     // compute stream waits for the halo
+// comm.hip
+int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count);
+int kmcf_comm_send_recv_halo(kmcf_matrix *m);
+int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);
+int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs);
+// matrix.hip
+int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
+                      const int *h_row_ptr, const int *h_col_global, const double *h_val, kmcf_matrix **out);

@@ -1,0 +1,709 @@
+// K path: sparsity pattern (initialize_sparsity_K), charge rule, fused K value
+// assembly, background-potential solve driver, potential gather, global heat.
+//
+// Reference -> here:
+//   calc_nnz_per_row / assemble_K_indices_gpu_off_diagonal_block: O(n_loc * n_cols)
+//   distance scans (src/iterative_solvers_gpu.cu:96-157, "20 min" at 40 nm, README.md:13)
+//     -> uniform cell list (edge = nn_dist), 27 cells per row, two passes (count, fill+sort).
+//   calc_off_diagonal_dist + reduce_rows_into_diag (per block) + 2x reduce_contact_into_diag
+//   + insert_into_diag + inverse_diag + calc_rhs_for_A: 5 + 2*nb launches, one thread per
+//   row, 7 hipMalloc/hipFree per call (src/potential_solver_gpu.cu:857-1042, 1118-1126)
+//     -> one site-class kernel + ONE fused kernel, 16 lanes per row, no allocation per call.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "kmcf_internal.hpp"
+
+int kmcf_pcg_workspace(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats);
+
+namespace {
+
+constexpr int EL_OXYGEN_DEFECT = 1, EL_VACANCY = 2;  // src/utils.h:37-44
+
+// src/gpu_solvers.h:274-319
+__device__ __forceinline__ double site_dist_dev(double x1, double y1, double z1, double x2, double y2, double z2,
+                                                double ly, double lz, int pbc)
+{
+    if (pbc == 1) {
+        double dist_x = x1 - x2;
+        double fy = (y1 - y2) / ly;
+        fy -= round(fy);
+        double fz = (z1 - z2) / lz;
+        fz -= round(fz);
+        double dy = fy * ly, dz = fz * lz;
+        return sqrt(dist_x * dist_x + dy * dy + dz * dz);
+    }
+    double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+struct cell_grid {
+    double x0, y0, z0, inv_x, inv_y, inv_z;
+    int ncx, ncy, ncz;
+    int wrap_y, wrap_z;  // periodic wrap of neighbour cells (pbc)
+};
+
+__device__ __forceinline__ int cell_coord(double v, double v0, double inv, int nc)
+{
+    int c = (int)floor((v - v0) * inv);
+    return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+}
+
+// Visit every site j in the 27 cells around site i with col_lo <= j < col_hi and
+// dist(i,j) < cutoff; F(j) is called in cell order (NOT ascending j).
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour(const cell_grid &g, const int *__restrict__ cell_start,
+                                                   const int *__restrict__ cell_items,
+                                                   const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, int i, double cutoff,
+                                                   double ly, double lz, int pbc, int col_lo, int col_hi, F f)
+{
+    const double xi = x[i], yi = y[i], zi = z[i];
+    const int cx = cell_coord(xi, g.x0, g.inv_x, g.ncx);
+    const int cy = cell_coord(yi, g.y0, g.inv_y, g.ncy);
+    const int cz = cell_coord(zi, g.z0, g.inv_z, g.ncz);
+    for (int ax = cx - 1; ax <= cx + 1; ++ax) {
+        if (ax < 0 || ax >= g.ncx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int ay = cy + dy;
+            if (g.wrap_y) ay = (ay + g.ncy) % g.ncy;
+            else if (ay < 0 || ay >= g.ncy) continue;
+            for (int dz = -1; dz <= 1; ++dz) {
+                int az = cz + dz;
+                if (g.wrap_z) az = (az + g.ncz) % g.ncz;
+                else if (az < 0 || az >= g.ncz) continue;
+                const int cidx = (ax * g.ncy + ay) * g.ncz + az;
+                for (int t = cell_start[cidx]; t < cell_start[cidx + 1]; ++t) {
+                    const int j = cell_items[t];
+                    if (j < col_lo || j >= col_hi) continue;
+                    double d = site_dist_dev(xi, yi, zi, x[j], y[j], z[j], ly, lz, pbc);
+                    if (d < cutoff) f(j);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void pattern_count_kernel(
+    cell_grid g, const int *__restrict__ cell_start, const int *__restrict__ cell_items,
+    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+    double cutoff, double ly, double lz, int pbc, int row_site0, int n_rows, int col_lo, int col_hi,
+    int *__restrict__ nnz_per_row)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+        int cnt = 0;
+        for_each_neighbour(g, cell_start, cell_items, x, y, z, row_site0 + r, cutoff, ly, lz, pbc, col_lo, col_hi,
+                           [&](int) { ++cnt; });
+        nnz_per_row[r] = cnt;
+    }
+}
+
+// Fill columns (block-local: j - col_lo) and sort each row ascending, as the reference's
+// col = 0..size_j-1 scan produces them (src/iterative_solvers_gpu.cu:143-155).
+__global__ __launch_bounds__(KMCF_BLOCK) void pattern_fill_kernel(
+    cell_grid g, const int *__restrict__ cell_start, const int *__restrict__ cell_items,
+    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+    double cutoff, double ly, double lz, int pbc, int row_site0, int n_rows, int col_lo, int col_hi,
+    const int *__restrict__ row_ptr, int *__restrict__ col)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+        const int b = row_ptr[r];
+        int n = 0;
+        for_each_neighbour(g, cell_start, cell_items, x, y, z, row_site0 + r, cutoff, ly, lz, pbc, col_lo, col_hi,
+                           [&](int j) {
+                               // insertion into the sorted prefix col[b .. b+n)
+                               int v = j - col_lo, k = n;
+                               while (k > 0 && col[b + k - 1] > v) { col[b + k] = col[b + k - 1]; --k; }
+                               col[b + k] = v;
+                               ++n;
+                           });
+    }
+}
+
+// Brute-force variants = the reference loops verbatim in structure; used when the
+// periodic cell grid would have fewer than 3 cells along y or z.
+__global__ __launch_bounds__(KMCF_BLOCK) void pattern_brute_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+    double cutoff, double ly, double lz, int pbc, int row_site0, int n_rows, int col_lo, int col_hi,
+    const int *__restrict__ row_ptr, int *__restrict__ nnz_per_row, int *__restrict__ col)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+        const int i = row_site0 + r;
+        int n = 0;
+        for (int j = col_lo; j < col_hi; ++j) {
+            double d = site_dist_dev(x[i], y[i], z[i], x[j], y[j], z[j], ly, lz, pbc);
+            if (d < cutoff) {
+                if (col) col[row_ptr[r] + n] = j - col_lo;
+                ++n;
+            }
+        }
+        if (nnz_per_row) nnz_per_row[r] = n;
+    }
+}
+
+// populate_neighbor_list, src/neighbor_lists_gpu.cu:55-77: first nn neighbours in
+// ascending j, i != j, no pbc in this distance, -1 padding (:277).
+constexpr int NL_CAP = 160;
+__global__ __launch_bounds__(KMCF_BLOCK) void neighbor_list_kernel(
+    cell_grid g, const int *__restrict__ cell_start, const int *__restrict__ cell_items,
+    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+    double nn_dist, int N, int nn, int count, int displ, int *__restrict__ neigh_idx, int *__restrict__ overflow)
+{
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const int i = idx + displ;
+        int buf[NL_CAP];
+        int n = 0;
+        for_each_neighbour(g, cell_start, cell_items, x, y, z, i, nn_dist, 1.0, 1.0, 0, 0, N, [&](int j) {
+            if (j == i) return;
+            if (n >= NL_CAP) { *overflow = 1; return; }
+            int k = n;
+            while (k > 0 && buf[k - 1] > j) { buf[k] = buf[k - 1]; --k; }
+            buf[k] = j;
+            ++n;
+        });
+        for (int t = 0; t < nn; ++t) neigh_idx[(size_t)idx * nn + t] = (t < n) ? buf[t] : -1;
+    }
+}
+
+// ---------------------------------------------------------------- charge
+// update_charge, src/potential_solver_gpu.cu:12-63.  16 lanes per site.
+__device__ __forceinline__ bool is_metal_dev(const int *__restrict__ metals, int num_metals, int e)
+{
+    for (int k = 0; k < num_metals; ++k)
+        if (metals[k] == e) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void update_charge_kernel(
+    const int *__restrict__ element, int *__restrict__ charge, const int *__restrict__ neigh_idx, int nn,
+    const int *__restrict__ metals, int num_metals, int row_start, int row_count)
+{
+    constexpr int LPS = 16;
+    const int lane = threadIdx.x % LPS;
+    const int groups = (row_count + KMCF_BLOCK / LPS - 1) / (KMCF_BLOCK / LPS);
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int idx = grp * (KMCF_BLOCK / LPS) + threadIdx.x / LPS;
+        const bool valid = idx < row_count;
+        const int i = row_start + idx;
+        const int e = valid ? element[i] : -1;
+        int vnn = 0, metal_nb = 0;
+        if (e == EL_VACANCY || e == EL_OXYGEN_DEFECT) {
+            for (int t = lane; t < nn; t += LPS) {
+                int nb = neigh_idx[(size_t)idx * nn + t];
+                if (nb >= 0) {
+                    int en = element[nb];
+                    vnn += (en == EL_VACANCY);
+                    metal_nb |= is_metal_dev(metals, num_metals, en) ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPS / 2; off >= 1; off >>= 1) {
+            vnn += __shfl_xor(vnn, off, 64);
+            metal_nb |= __shfl_xor(metal_nb, off, 64);
+        }
+        if (valid && lane == 0) {
+            if (e == EL_VACANCY) charge[i] = (metal_nb || vnn >= 2) ? 0 : 2;
+            else if (e == EL_OXYGEN_DEFECT) charge[i] = metal_nb ? 0 : -2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K values
+// bit0: metal, bit1: uncharged vacancy  ->  G = high_G iff (cls_i & cls_j) != 0
+// (calc_off_diagonal_dist, src/potential_solver_gpu.cu:263-280)
+__global__ __launch_bounds__(KMCF_BLOCK) void site_class_kernel(const int *__restrict__ element,
+                                                                const int *__restrict__ charge,
+                                                                const int *__restrict__ metals, int num_metals,
+                                                                int N, unsigned char *__restrict__ cls)
+{
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < N; s += gridDim.x * blockDim.x) {
+        const int e = element[s];
+        unsigned char c = is_metal_dev(metals, num_metals, e) ? 1 : 0;
+        if (e == EL_VACANCY && charge[s] == 0) c |= 2;
+        cls[s] = c;
+    }
+}
+
+// One pass per row (LPR lanes): off-diagonal values, diagonal = sum of conductances to
+// interface neighbours + left + right contact sums, 1/diag, rhs = left*VL + right*VR.
+// Row sums are formed from integer counts (n_high*high_G + n_low*low_G): independent of
+// lane order and of the rank count (the reference adds the values block by block in
+// column order, src/potential_solver_gpu.cu:774-794 -- equal up to a few ulp).
+template <int LPR>
+__global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
+    int n_loc, int row_site0 /* N_left + displ */, int n_left, int n_interface,
+    const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ val,
+    const int *__restrict__ diag_pos, const int *__restrict__ halo_gid,
+    const int *__restrict__ left_row_ptr, const int *__restrict__ left_col,
+    const int *__restrict__ right_row_ptr, const int *__restrict__ right_col,
+    const unsigned char *__restrict__ cls, double high_G, double low_G, double VL, double VR,
+    double *__restrict__ diag_out, double *__restrict__ left_out, double *__restrict__ right_out,
+    double *__restrict__ dinv_out, double *__restrict__ rhs_out)
+{
+    constexpr int RPB = KMCF_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int groups = (n_loc + RPB - 1) / RPB;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int r = grp * RPB + threadIdx.x / LPR;
+        const bool valid = r < n_loc;
+        int nh = 0, nl = 0, lh = 0, ll = 0, rh = 0, rl = 0;
+        int dpos = -1;
+        if (valid) {
+            const unsigned char ci = cls[row_site0 + r];
+            dpos = diag_pos[r];
+            for (int j = row_ptr[r] + lane; j < row_ptr[r + 1]; j += LPR) {
+                if (j == dpos) continue;
+                const int c = col[j];
+                const int site = (c < n_loc) ? (row_site0 + c) : (n_left + halo_gid[c - n_loc]);
+                const bool high = (ci & cls[site]) != 0;
+                val[j] = high ? -high_G : -low_G;
+                nh += high; nl += !high;
+            }
+            for (int j = left_row_ptr[r] + lane; j < left_row_ptr[r + 1]; j += LPR) {
+                const bool high = (ci & cls[left_col[j]]) != 0;
+                lh += high; ll += !high;
+            }
+            for (int j = right_row_ptr[r] + lane; j < right_row_ptr[r + 1]; j += LPR) {
+                const bool high = (ci & cls[n_left + n_interface + right_col[j]]) != 0;
+                rh += high; rl += !high;
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off >= 1; off >>= 1) {
+            nh += __shfl_xor(nh, off, 64); nl += __shfl_xor(nl, off, 64);
+            lh += __shfl_xor(lh, off, 64); ll += __shfl_xor(ll, off, 64);
+            rh += __shfl_xor(rh, off, 64); rl += __shfl_xor(rl, off, 64);
+        }
+        if (valid && lane == 0) {
+            const double d = (double)nh * high_G + (double)nl * low_G;
+            const double l = (double)lh * high_G + (double)ll * low_G;
+            const double rr = (double)rh * high_G + (double)rl * low_G;
+            const double tot = d + l + rr;                 // insert_into_diag :807
+            if (dpos >= 0) val[dpos] = tot;
+            diag_out[r] = tot;
+            left_out[r] = l;
+            right_out[r] = rr;
+            dinv_out[r] = 1.0 / (d + l + rr);              // inverse_diag :828
+            rhs_out[r] = l * VL + rr * VR;                 // calc_rhs_for_A :452
+        }
+    }
+}
+
+// sum_AB_into_A, src/potential_solver_gpu.cu:832-843
+__global__ __launch_bounds__(KMCF_BLOCK) void sum_ab_kernel(double *__restrict__ A, const double *__restrict__ B, int N)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) A[i] += B[i];
+}
+
+// ---------------------------------------------------------------- heat
+__device__ __forceinline__ double block_sum_h(double v, double *lds4)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void power_partial_kernel(const double *__restrict__ p, int N, double *__restrict__ part)
+{
+    __shared__ double lds4[4];
+    double s = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) s += p[i];
+    double t = block_sum_h(s, lds4);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// reduce + update_temp_global, src/heat_solver_gpu.cu:41-49
+__global__ __launch_bounds__(KMCF_BLOCK) void temp_update_kernel(const double *__restrict__ part, int npart,
+                                                                 double *__restrict__ T_bg, double a_coeff, double b_coeff,
+                                                                 double number_steps, double C_thermal, double small_step)
+{
+    __shared__ double lds4[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npart; i += KMCF_BLOCK) s += part[i];
+    double P_tot = block_sum_h(s, lds4);
+    if (threadIdx.x == 0) {
+        double c_coeff = b_coeff + P_tot / C_thermal * small_step;
+        double T_intermediate = *T_bg;
+        int step = (int)number_steps;
+        *T_bg = c_coeff * (1.0 - pow(a_coeff, (double)step)) / (1.0 - a_coeff) + pow(a_coeff, (double)step) * T_intermediate;
+    }
+}
+
+int grid1d(int64_t n, int cap = 2048)
+{
+    int64_t g = (n + KMCF_BLOCK - 1) / KMCF_BLOCK;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------- host-side cell list
+struct host_cells {
+    cell_grid g;
+    int *d_cell_start = nullptr;
+    int *d_cell_items = nullptr;
+    bool usable = true;   // false: fall back to brute force (tiny periodic grids)
+    void release()
+    {
+        if (d_cell_start) hipFree(d_cell_start);
+        if (d_cell_items) hipFree(d_cell_items);
+        d_cell_start = d_cell_items = nullptr;
+    }
+};
+
+int build_cells(const double *d_x, const double *d_y, const double *d_z, int N, const double *lattice, int pbc,
+                double edge, host_cells *hc)
+{
+    std::vector<double> x(N), y(N), z(N);
+    KMCF_HIP(hipMemcpy(x.data(), d_x, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    KMCF_HIP(hipMemcpy(y.data(), d_y, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    KMCF_HIP(hipMemcpy(z.data(), d_z, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int s = 0; s < N; ++s) {
+        lo[0] = std::min(lo[0], x[s]); hi[0] = std::max(hi[0], x[s]);
+        lo[1] = std::min(lo[1], y[s]); hi[1] = std::max(hi[1], y[s]);
+        lo[2] = std::min(lo[2], z[s]); hi[2] = std::max(hi[2], z[s]);
+    }
+    if (N == 0) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 0; }
+    cell_grid &g = hc->g;
+    g.wrap_y = g.wrap_z = 0;
+    g.x0 = lo[0]; g.inv_x = 1.0 / edge; g.ncx = (int)std::floor((hi[0] - lo[0]) / edge) + 1;
+    if (pbc == 1) {
+        // periodic in y and z (src/gpu_solvers.h:290-309): cells tile [y0, y0 + L) exactly
+        int ny = (int)std::floor(lattice[1] / edge), nz = (int)std::floor(lattice[2] / edge);
+        if (ny < 3 || nz < 3 || hi[1] - lo[1] >= lattice[1] || hi[2] - lo[2] >= lattice[2]) { hc->usable = false; return KMCF_OK; }
+        g.y0 = lo[1]; g.ncy = ny; g.inv_y = ny / lattice[1]; g.wrap_y = 1;
+        g.z0 = lo[2]; g.ncz = nz; g.inv_z = nz / lattice[2]; g.wrap_z = 1;
+    } else {
+        g.y0 = lo[1]; g.inv_y = 1.0 / edge; g.ncy = (int)std::floor((hi[1] - lo[1]) / edge) + 1;
+        g.z0 = lo[2]; g.inv_z = 1.0 / edge; g.ncz = (int)std::floor((hi[2] - lo[2]) / edge) + 1;
+    }
+    const int64_t ncell = (int64_t)g.ncx * g.ncy * g.ncz;
+    KMCF_CHECK(ncell < (int64_t)1 << 30, KMCF_ERR_ARG, "cell grid too large (%lld cells)", (long long)ncell);
+    auto coord = [](double v, double v0, double inv, int nc) {
+        int c = (int)std::floor((v - v0) * inv);
+        return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+    };
+    std::vector<int> start((size_t)ncell + 1, 0), cid((size_t)N), items((size_t)std::max(N, 1));
+    for (int s = 0; s < N; ++s) {
+        int cx = coord(x[s], g.x0, g.inv_x, g.ncx), cy = coord(y[s], g.y0, g.inv_y, g.ncy), cz = coord(z[s], g.z0, g.inv_z, g.ncz);
+        cid[s] = (cx * g.ncy + cy) * g.ncz + cz;
+        start[cid[s] + 1]++;
+    }
+    for (int64_t cidx = 0; cidx < ncell; ++cidx) start[cidx + 1] += start[cidx];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int s = 0; s < N; ++s) items[fill[cid[s]]++] = s;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&hc->d_cell_start), start.size() * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&hc->d_cell_items), items.size() * sizeof(int)));
+    KMCF_HIP(hipMemcpy(hc->d_cell_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(hc->d_cell_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+// CSR pattern of rows (sites row_site0 .. +n_rows) against columns (sites col_lo .. col_hi).
+int build_pattern(const host_cells &hc, const double *d_x, const double *d_y, const double *d_z,
+                  const double *lattice, int pbc, double cutoff, int row_site0, int n_rows, int col_lo, int col_hi,
+                  std::vector<int> *row_ptr, std::vector<int> *col, hipStream_t st)
+{
+    row_ptr->assign((size_t)n_rows + 1, 0);
+    col->clear();
+    if (n_rows == 0) return KMCF_OK;
+    int *d_cnt = nullptr, *d_rp = nullptr, *d_col = nullptr;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_cnt), (size_t)n_rows * sizeof(int)));
+    const int grid = grid1d(n_rows, 1 << 20);
+    if (hc.usable)
+        pattern_count_kernel<<<grid, KMCF_BLOCK, 0, st>>>(hc.g, hc.d_cell_start, hc.d_cell_items, d_x, d_y, d_z, cutoff,
+                                                          lattice[1], lattice[2], pbc, row_site0, n_rows, col_lo, col_hi, d_cnt);
+    else
+        pattern_brute_kernel<<<grid, KMCF_BLOCK, 0, st>>>(d_x, d_y, d_z, cutoff, lattice[1], lattice[2], pbc, row_site0,
+                                                          n_rows, col_lo, col_hi, nullptr, d_cnt, nullptr);
+    KMCF_HIP(hipGetLastError());
+    std::vector<int> cnt((size_t)n_rows);
+    KMCF_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, st));
+    KMCF_HIP(hipStreamSynchronize(st));
+    int64_t nnz = 0;
+    for (int r = 0; r < n_rows; ++r) { nnz += cnt[r]; (*row_ptr)[r + 1] = (int)nnz; }
+    KMCF_CHECK(nnz < (int64_t)INT32_MAX, KMCF_ERR_ARG, "pattern has %lld nnz: exceeds int32 indexing", (long long)nnz);
+    col->resize((size_t)nnz);
+    if (nnz > 0) {
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_rp), ((size_t)n_rows + 1) * sizeof(int)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_col), (size_t)nnz * sizeof(int)));
+        KMCF_HIP(hipMemcpyAsync(d_rp, row_ptr->data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        if (hc.usable)
+            pattern_fill_kernel<<<grid, KMCF_BLOCK, 0, st>>>(hc.g, hc.d_cell_start, hc.d_cell_items, d_x, d_y, d_z, cutoff,
+                                                             lattice[1], lattice[2], pbc, row_site0, n_rows, col_lo, col_hi, d_rp, d_col);
+        else
+            pattern_brute_kernel<<<grid, KMCF_BLOCK, 0, st>>>(d_x, d_y, d_z, cutoff, lattice[1], lattice[2], pbc, row_site0,
+                                                              n_rows, col_lo, col_hi, d_rp, nullptr, d_col);
+        KMCF_HIP(hipGetLastError());
+        KMCF_HIP(hipMemcpyAsync(col->data(), d_col, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, st));
+        KMCF_HIP(hipStreamSynchronize(st));
+        hipFree(d_rp);
+        hipFree(d_col);
+    }
+    hipFree(d_cnt);
+    return KMCF_OK;
+}
+
+template <typename T>
+int upload(T **d, const std::vector<T> &h)
+{
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(d), std::max<size_t>(h.size(), 1) * sizeof(T)));
+    if (!h.empty()) KMCF_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+}  // namespace
+
+extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const double *d_y, const double *d_z,
+                                          const double *h_lattice, int N, int pbc, double nn_dist, int N_contact,
+                                          const int *h_counts, const int *h_displs, kmcf_kstate **out)
+{
+    KMCF_CHECK(c && d_x && d_y && d_z && h_lattice && h_counts && h_displs && out, KMCF_ERR_ARG,
+               "kmcf_initialize_sparsity_K: null argument");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_initialize_sparsity_K: host-only communicator");
+    KMCF_CHECK(N > 2 * N_contact && N_contact >= 0, KMCF_ERR_ARG, "kmcf_initialize_sparsity_K: N=%d, N_contact=%d", N, N_contact);
+    KMCF_HIP(hipSetDevice(c->device));
+    const int N_left = N_contact, N_right = N_contact;
+    const int N_interface = N - (N_left + N_right);             // iterative_solvers_gpu.cu:271-273
+    const int n_loc = h_counts[c->rank], disp = h_displs[c->rank];
+    kmcf_kstate *k = new kmcf_kstate();
+    k->comm = c; k->N = N; k->N_left = N_left; k->N_right = N_right; k->N_interface = N_interface;
+
+    host_cells hc;
+    KMCF_TRY(build_cells(d_x, d_y, d_z, N, h_lattice, pbc, nn_dist, &hc));
+    int rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left, N_left + N_interface,
+                           &k->h_row_ptr, &k->h_col, c->stream);
+    if (rc == KMCF_OK)
+        rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, 0, N_left,
+                           &k->h_left_row_ptr, &k->h_left_col, c->stream);          // :449-461
+    if (rc == KMCF_OK)
+        rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left + N_interface, N,
+                           &k->h_right_row_ptr, &k->h_right_col, c->stream);        // :463-474
+    hc.release();
+    if (rc != KMCF_OK) { delete k; return rc; }
+
+    rc = kmcf_matrix_build(c, N_interface, h_counts, h_displs, k->h_row_ptr.data(), k->h_col.data(), nullptr, &k->K);
+    if (rc != KMCF_OK) { delete k; return rc; }
+    // position of the diagonal entry (insert_into_diag searches it every call, :795-814)
+    std::vector<int> diag_pos((size_t)n_loc, -1);
+    for (int r = 0; r < n_loc; ++r)
+        for (int j = k->h_row_ptr[r]; j < k->h_row_ptr[r + 1]; ++j)
+            if (k->h_col[j] == disp + r) { diag_pos[r] = j; break; }
+    KMCF_TRY(upload(&k->d_diag_pos, diag_pos));
+    KMCF_TRY(upload(&k->d_left_row_ptr, k->h_left_row_ptr));
+    KMCF_TRY(upload(&k->d_left_col, k->h_left_col));
+    KMCF_TRY(upload(&k->d_right_row_ptr, k->h_right_row_ptr));
+    KMCF_TRY(upload(&k->d_right_col, k->h_right_col));
+    const size_t nb = std::max(n_loc, 1) * sizeof(double);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_cls), std::max(N, 1)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_diag), nb));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_left), nb));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_right), nb));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_rhs), nb));
+    *out = k;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_kstate_destroy(kmcf_kstate *k)
+{
+    if (!k) return KMCF_OK;
+    if (k->comm && k->comm->device >= 0) {
+        hipSetDevice(k->comm->device);
+        hipStreamSynchronize(k->comm->stream);
+        void *ptrs[] = {k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_diag_pos, k->d_cls,
+                        k->d_diag, k->d_left, k->d_right, k->d_rhs, k->d_gather};
+        for (void *p : ptrs)
+            if (p) hipFree(p);
+    }
+    kmcf_matrix_destroy(k->K);
+    delete k;
+    return KMCF_OK;
+}
+
+extern "C" kmcf_matrix *kmcf_kstate_matrix(kmcf_kstate *k) { return k ? k->K : nullptr; }
+
+extern "C" int kmcf_kstate_pattern(const kmcf_kstate *k, int which, int *h_row_ptr, int *h_col, int64_t *nnz)
+{
+    KMCF_CHECK(k && which >= 0 && which <= 2, KMCF_ERR_ARG, "kmcf_kstate_pattern: bad argument");
+    const std::vector<int> &rp = which == 0 ? k->h_row_ptr : (which == 1 ? k->h_left_row_ptr : k->h_right_row_ptr);
+    const std::vector<int> &cl = which == 0 ? k->h_col : (which == 1 ? k->h_left_col : k->h_right_col);
+    if (nnz) *nnz = (int64_t)cl.size();
+    if (h_row_ptr) memcpy(h_row_ptr, rp.data(), rp.size() * sizeof(int));
+    if (h_col && !cl.empty()) memcpy(h_col, cl.data(), cl.size() * sizeof(int));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *d_site_charge, const int *d_neigh_idx,
+                                  int N, int nn, const int *d_metals, int num_metals, const int *h_count, const int *h_displ)
+{
+    KMCF_CHECK(c && d_site_element && d_site_charge && d_neigh_idx && d_metals && h_count && h_displ, KMCF_ERR_ARG,
+               "kmcf_update_charge: null argument");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_update_charge: host-only communicator");
+    KMCF_CHECK(nn > 0 && N >= 0, KMCF_ERR_ARG, "kmcf_update_charge: bad sizes");
+    KMCF_HIP(hipSetDevice(c->device));
+    const int count = h_count[c->rank], displ = h_displ[c->rank];
+    KMCF_CHECK(displ >= 0 && displ + count <= N, KMCF_ERR_ARG, "kmcf_update_charge: rows [%d,%d) outside N=%d", displ, displ + count, N);
+    if (count > 0) {
+        update_charge_kernel<<<grid1d((int64_t)count * 16), KMCF_BLOCK, 0, c->stream>>>(
+            d_site_element, d_site_charge, d_neigh_idx, nn, d_metals, num_metals, displ, count);
+        KMCF_HIP(hipGetLastError());
+    }
+    KMCF_TRY(kmcf_comm_allgatherv_int(c, d_site_charge, h_count, h_displ));   // MPI_Allgatherv, :82-83
+    KMCF_HIP(hipStreamSynchronize(c->stream));                                   // hipDeviceSynchronize, :80
+    return KMCF_OK;
+}
+
+static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                            const int *d_metals, int num_metals, double Vd, double high_G, double low_G)
+{
+    kmcf_comm *c = k->comm;
+    kmcf_matrix *m = k->K;
+    site_class_kernel<<<grid1d(k->N), KMCF_BLOCK, 0, c->stream>>>(d_site_element, d_site_charge, d_metals, num_metals, k->N, k->d_cls);
+    KMCF_HIP(hipGetLastError());
+    if (m->n_loc > 0) {
+        constexpr int LPR = 16;
+        k_assemble_kernel<LPR><<<grid1d((int64_t)m->n_loc * LPR), KMCF_BLOCK, 0, c->stream>>>(
+            m->n_loc, k->N_left + m->row0, k->N_left, k->N_interface, m->d_row_ptr, m->d_col, m->d_val, k->d_diag_pos,
+            m->d_halo_gid, k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls, high_G, low_G,
+            -Vd / 2, Vd / 2,                                                     // :866-867
+            k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs);
+        KMCF_HIP(hipGetLastError());
+    }
+    k->assembled = true;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_k_assemble(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                               const int *d_metals, int num_metals, double Vd, double high_G, double low_G)
+{
+    KMCF_CHECK(k && d_site_element && d_site_charge && d_metals, KMCF_ERR_ARG, "kmcf_k_assemble: null argument");
+    KMCF_HIP(hipSetDevice(k->comm->device));
+    KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G));
+    KMCF_HIP(hipStreamSynchronize(k->comm->stream));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_k_get_vectors(const kmcf_kstate *k, double *h_diag, double *h_dinv, double *h_rhs,
+                                  double *h_left, double *h_right)
+{
+    KMCF_CHECK(k, KMCF_ERR_ARG, "kmcf_k_get_vectors: null state");
+    KMCF_CHECK(k->assembled, KMCF_ERR_STATE, "kmcf_k_get_vectors: call kmcf_k_assemble first");
+    KMCF_HIP(hipSetDevice(k->comm->device));
+    KMCF_HIP(hipStreamSynchronize(k->comm->stream));
+    const size_t bytes = (size_t)k->K->n_loc * sizeof(double);
+    if (h_diag) KMCF_HIP(hipMemcpy(h_diag, k->d_diag, bytes, hipMemcpyDeviceToHost));
+    if (h_dinv) KMCF_HIP(hipMemcpy(h_dinv, k->K->d_dinv, bytes, hipMemcpyDeviceToHost));
+    if (h_rhs) KMCF_HIP(hipMemcpy(h_rhs, k->d_rhs, bytes, hipMemcpyDeviceToHost));
+    if (h_left) KMCF_HIP(hipMemcpy(h_left, k->d_left, bytes, hipMemcpyDeviceToHost));
+    if (h_right) KMCF_HIP(hipMemcpy(h_right, k->d_right, bytes, hipMemcpyDeviceToHost));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                                                const int *d_metals, int num_metals, double *d_site_potential_boundary,
+                                                int N, int N_left_tot, int N_right_tot, double Vd,
+                                                double high_G, double low_G, kmcf_solve_stats_t *stats)
+{
+    KMCF_CHECK(k && d_site_element && d_site_charge && d_metals && d_site_potential_boundary, KMCF_ERR_ARG,
+               "kmcf_background_potential_sparse: null argument");
+    KMCF_CHECK(N == k->N && N_left_tot == k->N_left && N_right_tot == k->N_right, KMCF_ERR_ARG,
+               "kmcf_background_potential_sparse: N/N_left/N_right (%d,%d,%d) differ from the pattern's (%d,%d,%d)",
+               N, N_left_tot, N_right_tot, k->N, k->N_left, k->N_right);
+    kmcf_comm *c = k->comm;
+    kmcf_matrix *m = k->K;
+    KMCF_CHECK(c->connected, KMCF_ERR_COMM, "kmcf_background_potential_sparse: communicator not connected");
+    KMCF_HIP(hipSetDevice(c->device));
+    hipEvent_t a0, a1;
+    KMCF_HIP(hipEventCreate(&a0));
+    KMCF_HIP(hipEventCreate(&a1));
+    KMCF_HIP(hipEventRecord(a0, c->stream));
+    KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G));
+    KMCF_HIP(hipEventRecord(a1, c->stream));
+    const size_t bytes = (size_t)m->n_loc * sizeof(double);
+    // the initial guess is the current potential inside the device, solved in place (:861)
+    double *v_soln = d_site_potential_boundary + N_left_tot + m->row0;
+    KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipMemcpyAsync(m->d_x, v_soln, bytes, hipMemcpyDeviceToDevice, c->stream));
+    const double relative_tolerance = 1e-14 * k->N_interface;   // :885
+    const int max_iterations = 10000;                           // :886
+    KMCF_TRY(kmcf_pcg_workspace(m, true, relative_tolerance, max_iterations, 0, stats));
+    KMCF_HIP(hipMemcpyAsync(v_soln, m->d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    if (stats) {
+        float ms = 0.f;
+        KMCF_HIP(hipEventElapsedTime(&ms, a0, a1));
+        stats->ms_assembly = ms;
+    }
+    hipEventDestroy(a0);
+    hipEventDestroy(a1);
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_potential_boundary,
+                                             double *d_site_potential_charge, int N, int num_atoms_first_layer)
+{
+    KMCF_CHECK(k && d_site_potential_boundary && d_site_potential_charge, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: null argument");
+    KMCF_CHECK(N == k->N && num_atoms_first_layer == k->N_left, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: size mismatch");
+    kmcf_comm *c = k->comm;
+    KMCF_HIP(hipSetDevice(c->device));
+    // MPI_Gatherv to rank 0 (src/kmc_main.cpp:367-384) + MPI_Bcast (potential_solver_gpu.cu:1133-1136)
+    KMCF_TRY(kmcf_comm_allgatherv_double(c, d_site_potential_boundary + num_atoms_first_layer,
+                                         k->K->counts.data(), k->K->displs.data()));
+    sum_ab_kernel<<<grid1d(N), KMCF_BLOCK, 0, c->stream>>>(d_site_potential_charge, d_site_potential_boundary, N);
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,
+                                              double a_coeff, double b_coeff, double number_steps,
+                                              double C_thermal, double small_step)
+{
+    KMCF_CHECK(c && d_site_power && d_T_bg && N >= 0, KMCF_ERR_ARG, "kmcf_update_temperature_global: bad argument");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_update_temperature_global: host-only communicator");
+    KMCF_HIP(hipSetDevice(c->device));
+    double *d_part = nullptr;
+    const int g = grid1d(N, 1024);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_part), (size_t)g * sizeof(double)));
+    power_partial_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(d_site_power, N, d_part);
+    KMCF_HIP(hipGetLastError());
+    temp_update_kernel<<<1, KMCF_BLOCK, 0, c->stream>>>(d_part, g, d_T_bg, a_coeff, b_coeff, number_steps, C_thermal, small_step);
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_part);
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_neighbor_list(kmcf_comm *c, const double *d_x, const double *d_y, const double *d_z, int N,
+                                  double nn_dist, int nn, int count, int displ, int *d_neigh_idx)
+{
+    KMCF_CHECK(c && d_x && d_y && d_z && d_neigh_idx, KMCF_ERR_ARG, "kmcf_neighbor_list: null argument");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_neighbor_list: host-only communicator");
+    KMCF_CHECK(nn > 0 && nn <= NL_CAP && count >= 0 && displ >= 0 && displ + count <= N, KMCF_ERR_ARG, "kmcf_neighbor_list: bad sizes");
+    KMCF_HIP(hipSetDevice(c->device));
+    host_cells hc;
+    const double lattice[3] = {1, 1, 1};
+    KMCF_TRY(build_cells(d_x, d_y, d_z, N, lattice, 0, nn_dist, &hc));
+    int *d_over = nullptr;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_over), sizeof(int)));
+    KMCF_HIP(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+    if (count > 0) {
+        neighbor_list_kernel<<<grid1d(count, 1 << 20), KMCF_BLOCK, 0, c->stream>>>(
+            hc.g, hc.d_cell_start, hc.d_cell_items, d_x, d_y, d_z, nn_dist, N, nn, count, displ, d_neigh_idx, d_over);
+        KMCF_HIP(hipGetLastError());
+    }
+    int over = 0;
+    KMCF_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_over);
+    hc.release();
+    KMCF_CHECK(!over, KMCF_ERR_ARG, "kmcf_neighbor_list: a site has more than %d neighbours within nn_dist", NL_CAP);
+    return KMCF_OK;
+}

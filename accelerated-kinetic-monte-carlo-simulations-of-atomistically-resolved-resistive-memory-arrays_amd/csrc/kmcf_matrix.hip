@@ -1,0 +1,270 @@
+// Distributed CSR matrix: host-side planning (neighbour discovery, halo lists,
+// compact-halo column remap) and device upload.
+//
+// Reference behaviour mirrored (dist_iterative/dist_matrix.cpp):
+//   neighbours        cyclic order starting at own rank, only ranks whose column
+//                     range holds a nonzero of our rows            (:237-278)
+//   cols_per_neighbour sorted unique block-local columns = what we receive (:451-487)
+//   rows_per_neighbour local rows with a nonzero in the block = what we send;
+//                     valid because the matrix is structurally symmetric (:3, :418-448)
+// MI355X layout (differs from the reference on purpose):
+//   ONE CSR per rank whose column ids are remapped to [0,n_loc) (own block) and
+//   n_loc + compact halo slot (neighbour blocks), so the SpMV is a single kernel
+//   over a single x vector [p_local | p_halo] and received halos need no unpack
+//   (the reference keeps one CSR + one full-length dense vector per neighbour and
+//   scatters every received buffer, dist_vector.cpp:3-42, utils_cg.cu:52-98).
+#include <algorithm>
+#include <cstring>
+
+#include "kmcf_internal.hpp"
+
+namespace {
+
+template <typename T>
+int dev_upload(T **d, const std::vector<T> &h)
+{
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(d), bytes));
+    if (!h.empty()) KMCF_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+template <typename T>
+int dev_alloc(T **d, size_t n)
+{
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(d), std::max<size_t>(n, 1) * sizeof(T)));
+    KMCF_HIP(hipMemset(*d, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    return KMCF_OK;
+}
+
+}  // namespace
+
+int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
+                      const int *h_row_ptr, const int *h_col_global, const double *h_val, kmcf_matrix **out)
+{
+    KMCF_CHECK(c && counts && displs && h_row_ptr && out, KMCF_ERR_ARG, "kmcf_matrix_build: null argument");
+    const int P = c->nranks, rank = c->rank;
+    {
+        int64_t tot = 0;
+        for (int q = 0; q < P; ++q) {
+            KMCF_CHECK(counts[q] >= 0 && displs[q] == (int)tot, KMCF_ERR_ARG,
+                       "kmcf_matrix_build: counts/displs are not a contiguous partition at rank %d", q);
+            tot += counts[q];
+        }
+        KMCF_CHECK(tot == matrix_size, KMCF_ERR_ARG, "kmcf_matrix_build: counts sum %lld != matrix_size %d",
+                   (long long)tot, matrix_size);
+    }
+    kmcf_matrix *m = new kmcf_matrix();
+    m->comm = c;
+    m->matrix_size = matrix_size;
+    m->counts.assign(counts, counts + P);
+    m->displs.assign(displs, displs + P);
+    m->n_loc = counts[rank];
+    m->row0 = displs[rank];
+    const int n_loc = m->n_loc;
+    KMCF_CHECK(h_row_ptr[0] == 0, KMCF_ERR_ARG, "kmcf_matrix_build: row_ptr[0] != 0");
+    m->nnz = h_row_ptr[n_loc];
+    const int64_t nnz = m->nnz;
+    KMCF_CHECK(nnz == 0 || h_col_global, KMCF_ERR_ARG, "kmcf_matrix_build: null column array");
+
+    // owner of a global column (ranks with zero rows are skipped by upper_bound on displs)
+    auto owner = [&](int col) {
+        int q = int(std::upper_bound(displs, displs + P, col) - displs) - 1;
+        while (q > 0 && counts[q] == 0) --q;  // displs repeats for empty ranks
+        return q;
+    };
+
+    // pass 1: per-owner flags of referenced block-local columns, nnz per owner
+    std::vector<int64_t> nnz_owner(P, 0);
+    std::vector<std::vector<unsigned char>> col_flag(P);
+    std::vector<int> own(nnz);
+    for (int r = 0; r < n_loc; ++r) {
+        KMCF_CHECK(h_row_ptr[r + 1] >= h_row_ptr[r], KMCF_ERR_ARG, "kmcf_matrix_build: row_ptr not monotone at row %d", r);
+        for (int j = h_row_ptr[r]; j < h_row_ptr[r + 1]; ++j) {
+            int cg = h_col_global[j];
+            KMCF_CHECK(cg >= 0 && cg < matrix_size, KMCF_ERR_ARG, "kmcf_matrix_build: column %d out of range at nnz %d", cg, j);
+            int q = owner(cg);
+            own[j] = q;
+            if (col_flag[q].empty()) col_flag[q].assign((size_t)counts[q], 0);
+            col_flag[q][cg - displs[q]] = 1;
+            nnz_owner[q]++;
+        }
+    }
+    // neighbours in cyclic order from self; self is always block 0 (the reference's
+    // initialize_sparsity_K always has the diagonal in the pattern)
+    m->neighbours.clear();
+    for (int k = 0; k < P; ++k) {
+        int q = (rank + k) % P;
+        if (k == 0 || nnz_owner[q] > 0) {
+            m->neighbours.push_back(q);
+            m->nnz_per_neighbour.push_back((int)nnz_owner[q]);
+        }
+    }
+    m->number_of_neighbours = (int)m->neighbours.size();
+    const int nnb = m->number_of_neighbours;
+    std::vector<int> nb_index(P, -1);
+    for (int k = 0; k < nnb; ++k) nb_index[m->neighbours[k]] = k;
+
+    // receive lists (sorted unique block-local columns) and compact slot maps
+    m->cols_per_neighbour.assign(nnb, {});
+    m->rows_per_neighbour.assign(nnb, {});
+    m->halo_offset.assign(nnb, 0);
+    m->send_offset.assign(nnb, 0);
+    std::vector<std::vector<int>> slot_of(nnb);  // block-local column -> slot in block
+    int halo = 0;
+    for (int k = 0; k < nnb; ++k) {
+        int q = m->neighbours[k];
+        auto &flag = col_flag[q];
+        auto &cols = m->cols_per_neighbour[k];
+        for (int cidx = 0; cidx < (int)flag.size(); ++cidx)
+            if (flag[cidx]) cols.push_back(cidx);
+        if (k >= 1) {
+            m->halo_offset[k] = halo;
+            slot_of[k].assign((size_t)counts[q], -1);
+            for (int s = 0; s < (int)cols.size(); ++s) slot_of[k][cols[s]] = s;
+            halo += (int)cols.size();
+        }
+    }
+    m->n_halo = halo;
+
+    // remapped CSR + send lists + boundary rows
+    std::vector<int> col_local(nnz);
+    std::vector<unsigned char> is_boundary((size_t)n_loc, 0);
+    std::vector<int> last_row_seen(nnb, -1);
+    for (int r = 0; r < n_loc; ++r) {
+        for (int j = h_row_ptr[r]; j < h_row_ptr[r + 1]; ++j) {
+            int q = own[j], k = nb_index[q];
+            int cl = h_col_global[j] - displs[q];
+            if (k == 0) {
+                col_local[j] = cl;
+            } else {
+                col_local[j] = n_loc + m->halo_offset[k] + slot_of[k][cl];
+                is_boundary[r] = 1;
+            }
+            if (last_row_seen[k] != r) {
+                last_row_seen[k] = r;
+                m->rows_per_neighbour[k].push_back(r);
+            }
+        }
+    }
+    std::vector<int> boundary_rows;
+    for (int r = 0; r < n_loc; ++r)
+        if (is_boundary[r]) boundary_rows.push_back(r);
+    m->n_boundary_rows = (int)boundary_rows.size();
+    std::vector<int> send_idx;
+    int so = 0;
+    for (int k = 1; k < nnb; ++k) {
+        m->send_offset[k] = so;
+        send_idx.insert(send_idx.end(), m->rows_per_neighbour[k].begin(), m->rows_per_neighbour[k].end());
+        so += (int)m->rows_per_neighbour[k].size();
+    }
+    m->n_send = so;
+    std::vector<int> halo_gid((size_t)m->n_halo);
+    for (int k = 1; k < nnb; ++k)
+        for (int s = 0; s < (int)m->cols_per_neighbour[k].size(); ++s)
+            halo_gid[m->halo_offset[k] + s] = displs[m->neighbours[k]] + m->cols_per_neighbour[k][s];
+
+    if (c->device < 0) {  // host-only planning communicator: no device state
+        *out = m;
+        return KMCF_OK;
+    }
+
+    KMCF_HIP(hipSetDevice(c->device));
+    std::vector<int> rp(h_row_ptr, h_row_ptr + n_loc + 1);
+    KMCF_TRY(dev_upload(&m->d_row_ptr, rp));
+    KMCF_TRY(dev_upload(&m->d_col, col_local));
+    if (h_val) {
+        std::vector<double> v(h_val, h_val + nnz);
+        KMCF_TRY(dev_upload(&m->d_val, v));
+    } else {
+        KMCF_TRY(dev_alloc(&m->d_val, (size_t)nnz));
+    }
+    if (m->n_halo > 0) {
+        KMCF_TRY(dev_upload(&m->d_is_boundary, is_boundary));
+        KMCF_TRY(dev_upload(&m->d_boundary_rows, boundary_rows));
+        KMCF_TRY(dev_upload(&m->d_send_idx, send_idx));
+        KMCF_TRY(dev_alloc(&m->d_send_buf, (size_t)m->n_send));
+        KMCF_TRY(dev_upload(&m->d_halo_gid, halo_gid));
+    }
+    KMCF_TRY(dev_alloc(&m->d_p, (size_t)n_loc + m->n_halo + 2));
+    KMCF_TRY(dev_alloc(&m->d_Ap, (size_t)n_loc + 2));
+    KMCF_TRY(dev_alloc(&m->d_r, (size_t)n_loc + 2));
+    KMCF_TRY(dev_alloc(&m->d_x, (size_t)n_loc + 2));
+    KMCF_TRY(dev_alloc(&m->d_dinv, (size_t)n_loc + 2));
+    KMCF_TRY(dev_alloc(&m->d_part_a, (size_t)2 * KMCF_MAX_PARTIALS));
+    KMCF_TRY(dev_alloc(&m->d_part_b, (size_t)KMCF_MAX_PARTIALS));
+    KMCF_TRY(dev_alloc(&m->d_part_c, (size_t)KMCF_MAX_PARTIALS));
+    KMCF_TRY(dev_alloc(&m->d_S, 1));
+    KMCF_TRY(kmcf_spmv_plan(m));
+    *out = m;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_matrix_create_csr(kmcf_comm *c, int matrix_size, const int *h_counts, const int *h_displs,
+                                      const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                                      kmcf_matrix **out)
+{
+    return kmcf_matrix_build(c, matrix_size, h_counts, h_displs, h_row_ptr, h_col_global, h_val, out);
+}
+
+extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
+{
+    if (!m) return KMCF_OK;
+    if (m->comm && m->comm->device >= 0) {
+        hipSetDevice(m->comm->device);
+        hipStreamSynchronize(m->comm->stream);
+        hipStreamSynchronize(m->comm->comm_stream);
+        void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
+                        m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
+                        m->d_part_a, m->d_part_b, m->d_part_c, m->d_S};
+        for (void *p : ptrs)
+            if (p) hipFree(p);
+    }
+    delete m;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info)
+{
+    KMCF_CHECK(m && info, KMCF_ERR_ARG, "kmcf_matrix_info: null argument");
+    info->matrix_size = m->matrix_size;
+    info->rows_this_rank = m->n_loc;
+    info->nnz = m->nnz;
+    info->number_of_neighbours = m->number_of_neighbours;
+    info->halo_cols = m->n_halo;
+    info->send_rows = m->n_send;
+    info->boundary_rows = m->n_boundary_rows;
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_matrix_neighbour(const kmcf_matrix *m, int k, int *neighbour_rank, int *nnz_block,
+                                     int *ncols, int *h_cols, int *nrows, int *h_rows)
+{
+    KMCF_CHECK(m && k >= 0 && k < m->number_of_neighbours, KMCF_ERR_ARG, "kmcf_matrix_neighbour: k=%d out of range", k);
+    if (neighbour_rank) *neighbour_rank = m->neighbours[k];
+    if (nnz_block) *nnz_block = m->nnz_per_neighbour[k];
+    if (ncols) *ncols = (int)m->cols_per_neighbour[k].size();
+    if (nrows) *nrows = (int)m->rows_per_neighbour[k].size();
+    if (h_cols) memcpy(h_cols, m->cols_per_neighbour[k].data(), m->cols_per_neighbour[k].size() * sizeof(int));
+    if (h_rows) memcpy(h_rows, m->rows_per_neighbour[k].data(), m->rows_per_neighbour[k].size() * sizeof(int));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val)
+{
+    KMCF_CHECK(m && h_val, KMCF_ERR_ARG, "kmcf_matrix_set_values: null argument");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_set_values: host-only matrix");
+    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_HIP(hipMemcpy(m->d_val, h_val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+extern "C" int kmcf_matrix_get_values(const kmcf_matrix *m, double *h_val)
+{
+    KMCF_CHECK(m && h_val, KMCF_ERR_ARG, "kmcf_matrix_get_values: null argument");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_get_values: host-only matrix");
+    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_HIP(hipStreamSynchronize(m->comm->stream));
+    KMCF_HIP(hipMemcpy(h_val, m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return KMCF_OK;
+}

@@ -1,0 +1,348 @@
+"""Host-side mirror of the reference's call surface for the field-solve path.
+
+Names, argument meaning and side effects follow src/gpu_solvers.h:36-263,
+src/gpu_buffers.h, src/KMC_comm.h and dist_iterative/ so that the parity tests
+read like calls into the reference.  Every function forwards to the C ABI of
+libkmcfield.so (include/kmcfield.h); torch is used only to own device memory
+and (optionally) to bootstrap the RCCL communicator.  No compute happens here
+and nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _L
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _ia(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _da(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class KMC_comm:
+    """Partition tables of src/KMC_comm.h:225-289 (split=false: every module uses
+    all ranks) plus this rank's libkmcfield communicator."""
+
+    def __init__(self, nrows_K, nrows_T, nrows_pairwise, nrows_events, rank=0, size=1, device=0):
+        self.lib = _L.load()
+        self.rank_K = self.rank_events = self.rank_pairwise = rank
+        self.size_K = self.size_events = self.size_pairwise = size
+        self.counts_K, self.displs_K = self.partition(nrows_K, size)
+        self.counts_pairwise, self.displs_pairwise = self.partition(nrows_pairwise, size)
+        self.counts_events, self.displs_events = self.partition(nrows_events, size)
+        self.device = device
+        h = C.c_void_p()
+        _L.check(self.lib.kmcf_comm_create(C.byref(h), device, size, rank), "kmcf_comm_create")
+        self.handle = h
+
+    @staticmethod
+    def partition(nrows, size):
+        lib = _L.load()
+        counts = np.zeros(size, np.int32)
+        displs = np.zeros(size, np.int32)
+        _L.check(lib.kmcf_partition(int(nrows), int(size), counts.ctypes.data_as(C.POINTER(C.c_int)),
+                                    displs.ctypes.data_as(C.POINTER(C.c_int))), "kmcf_partition")
+        return counts, displs
+
+    def connect(self, dist=None):
+        """Bootstrap RCCL: rank 0 creates the unique id, torch.distributed (any
+        backend) broadcasts its 128 bytes, every rank joins.  No-op for 1 rank."""
+        if self.size_K == 1:
+            _L.check(self.lib.kmcf_comm_connect(self.handle, None), "kmcf_comm_connect")
+            return
+        assert dist is not None and dist.is_initialized(), "multi-rank groups need torch.distributed for bootstrap"
+        buf = (C.c_char * _L.KMCF_UNIQUE_ID_BYTES)()
+        if self.rank_K == 0:
+            _L.check(self.lib.kmcf_comm_unique_id(buf), "kmcf_comm_unique_id")
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+        use_cuda = dist.get_backend() == "nccl"
+        if use_cuda:
+            t = t.cuda(self.device)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        _L.check(self.lib.kmcf_comm_connect(self.handle, C.create_string_buffer(raw, len(raw))), "kmcf_comm_connect")
+
+    def sync(self):
+        _L.check(self.lib.kmcf_comm_sync(self.handle), "kmcf_comm_sync")
+
+    def close(self):
+        if self.handle:
+            self.lib.kmcf_comm_destroy(self.handle)
+            self.handle = None
+
+
+class GPUBuffers:
+    """Device SoA of src/gpu_buffers.h:12-162 (the members the K path touches).
+    Arrays are torch CUDA tensors; K_distributed is the libkmcfield K state."""
+
+    def __init__(self, N, site_element, site_x, site_y, site_z, nn, sigma, k, lattice, metals, device=0,
+                 site_power=None, T_bg=300.0):
+        dev = torch.device("cuda", device)
+        self.device = dev
+        self.N_ = int(N)
+        self.nn_ = int(nn)
+        self.num_metal_types_ = len(metals)
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.site_element = torch.as_tensor(np.asarray(site_element, np.int32), **i32)
+        self.site_x = torch.as_tensor(np.asarray(site_x, np.float64), **f64)
+        self.site_y = torch.as_tensor(np.asarray(site_y, np.float64), **f64)
+        self.site_z = torch.as_tensor(np.asarray(site_z, np.float64), **f64)
+        self.site_charge = torch.zeros(N, **i32)
+        self.site_potential_boundary = torch.zeros(N, **f64)
+        self.site_potential_charge = torch.zeros(N, **f64)
+        self.site_power = torch.zeros(N, **f64) if site_power is None else torch.as_tensor(site_power, **f64)
+        self.T_bg = torch.tensor([T_bg], **f64)
+        self.metal_types = torch.as_tensor(np.asarray(metals, np.int32), **i32)
+        self.lattice_host = np.asarray(lattice, np.float64)
+        self.sigma, self.k = float(sigma), float(k)
+        self.neigh_idx = None
+        self.K_distributed = None      # kmcf_kstate* (K_distributed + K_p_distributed + contact patterns)
+
+    def freeGPUmemory(self):
+        if self.K_distributed is not None:
+            _L.load().kmcf_kstate_destroy(self.K_distributed)
+            self.K_distributed = None
+
+
+# --------------------------------------------------------------------------
+# gpu_solvers.h surface
+# --------------------------------------------------------------------------
+
+def compute_neighbor_list(kmc_comm, gpubuf, nn_dist=3.5, max_num_neighbors=52):
+    """compute_neighbor_list (gpu_solvers.h:43; src/neighbor_lists_gpu.cu:252-292)."""
+    lib = _L.load()
+    count = int(kmc_comm.counts_events[kmc_comm.rank_events])
+    displ = int(kmc_comm.displs_events[kmc_comm.rank_events])
+    gpubuf.neigh_idx = torch.empty(max(count, 1) * max_num_neighbors, dtype=torch.int32, device=gpubuf.device)
+    gpubuf.nn_ = max_num_neighbors
+    _L.check(lib.kmcf_neighbor_list(kmc_comm.handle, _ptr(gpubuf.site_x), _ptr(gpubuf.site_y), _ptr(gpubuf.site_z),
+                                    gpubuf.N_, float(nn_dist), max_num_neighbors, count, displ,
+                                    _ptr(gpubuf.neigh_idx)), "kmcf_neighbor_list")
+
+
+def initialize_sparsity_K(gpubuf, pbc, nn_dist, num_atoms_contact, kmc_comm):
+    """initialize_sparsity_K (gpu_solvers.h:53; src/iterative_solvers_gpu.cu:262-488)."""
+    lib = _L.load()
+    h = C.c_void_p()
+    lat, latp = _da(gpubuf.lattice_host)
+    cnt, cntp = _ia(kmc_comm.counts_K)
+    dsp, dspp = _ia(kmc_comm.displs_K)
+    _L.check(lib.kmcf_initialize_sparsity_K(kmc_comm.handle, _ptr(gpubuf.site_x), _ptr(gpubuf.site_y),
+                                            _ptr(gpubuf.site_z), latp, gpubuf.N_, int(pbc), float(nn_dist),
+                                            int(num_atoms_contact), cntp, dspp, C.byref(h)),
+             "kmcf_initialize_sparsity_K")
+    gpubuf.K_distributed = h
+
+
+def update_charge_gpu(site_element, site_charge, neigh_idx, N, nn, metals, num_metals, count, displ, kmc_comm):
+    """update_charge_gpu (gpu_solvers.h:149; src/potential_solver_gpu.cu:66-85)."""
+    lib = _L.load()
+    cnt, cntp = _ia(count)
+    dsp, dspp = _ia(displ)
+    _L.check(lib.kmcf_update_charge(kmc_comm.handle, _ptr(site_element), _ptr(site_charge), _ptr(neigh_idx),
+                                    int(N), int(nn), _ptr(metals), int(num_metals), cntp, dspp), "kmcf_update_charge")
+
+
+def background_potential_gpu_sparse(gpubuf, N, N_left_tot, N_right_tot, Vd, pbc, high_G, low_G, nn_dist,
+                                    num_metals, kmc_step_count=0):
+    """background_potential_gpu_sparse (gpu_solvers.h:162; src/potential_solver_gpu.cu:846-1128).
+    Returns the solve statistics (the reference prints the iteration count on rank 0)."""
+    lib = _L.load()
+    st = _L.SolveStats()
+    _L.check(lib.kmcf_background_potential_sparse(gpubuf.K_distributed, _ptr(gpubuf.site_element),
+                                                  _ptr(gpubuf.site_charge), _ptr(gpubuf.metal_types), int(num_metals),
+                                                  _ptr(gpubuf.site_potential_boundary), int(N), int(N_left_tot),
+                                                  int(N_right_tot), float(Vd), float(high_G), float(low_G),
+                                                  C.byref(st)), "kmcf_background_potential_sparse")
+    return st.as_dict()
+
+
+def sum_and_gather_potential(gpubuf, num_atoms_first_layer, kmc_comm):
+    """sum_and_gather_potential (gpu_solvers.h:181; src/potential_solver_gpu.cu:1130-1151) including the
+    MPI_Gatherv of the solution done by the caller in the reference (src/kmc_main.cpp:367-384)."""
+    lib = _L.load()
+    _L.check(lib.kmcf_sum_and_gather_potential(gpubuf.K_distributed, _ptr(gpubuf.site_potential_boundary),
+                                               _ptr(gpubuf.site_potential_charge), gpubuf.N_,
+                                               int(num_atoms_first_layer)), "kmcf_sum_and_gather_potential")
+
+
+def update_temperatureglobal_gpu(site_power, T_bg, N, a_coeff, b_coeff, number_steps, C_thermal, small_step,
+                                 kmc_comm):
+    """update_temperatureglobal_gpu (gpu_solvers.h:231; src/heat_solver_gpu.cu:53-70)."""
+    lib = _L.load()
+    _L.check(lib.kmcf_update_temperature_global(kmc_comm.handle, _ptr(site_power), _ptr(T_bg), int(N),
+                                                float(a_coeff), float(b_coeff), float(number_steps),
+                                                float(C_thermal), float(small_step)),
+             "kmcf_update_temperature_global")
+
+
+# K-state inspection helpers used by the parity tests --------------------------------
+
+def k_assemble(gpubuf, Vd, high_G, low_G):
+    lib = _L.load()
+    _L.check(lib.kmcf_k_assemble(gpubuf.K_distributed, _ptr(gpubuf.site_element), _ptr(gpubuf.site_charge),
+                                 _ptr(gpubuf.metal_types), gpubuf.num_metal_types_, float(Vd), float(high_G),
+                                 float(low_G)), "kmcf_k_assemble")
+
+
+def k_pattern(gpubuf, which=0):
+    lib = _L.load()
+    mat = Distributed_matrix.from_handle(lib.kmcf_kstate_matrix(gpubuf.K_distributed))
+    n = mat.info()["rows_this_rank"]
+    nnz = C.c_int64()
+    _L.check(lib.kmcf_kstate_pattern(gpubuf.K_distributed, which, None, None, C.byref(nnz)), "kmcf_kstate_pattern")
+    rp = np.zeros(n + 1, np.int32)
+    col = np.zeros(max(nnz.value, 1), np.int32)
+    _L.check(lib.kmcf_kstate_pattern(gpubuf.K_distributed, which, rp.ctypes.data_as(C.POINTER(C.c_int)),
+                                     col.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nnz)), "kmcf_kstate_pattern")
+    return rp, col[:nnz.value]
+
+
+def k_vectors(gpubuf):
+    lib = _L.load()
+    mat = Distributed_matrix.from_handle(lib.kmcf_kstate_matrix(gpubuf.K_distributed))
+    n = mat.info()["rows_this_rank"]
+    out = {k: np.zeros(max(n, 1)) for k in ("diag", "dinv", "rhs", "left", "right")}
+    p = {k: v.ctypes.data_as(C.POINTER(C.c_double)) for k, v in out.items()}
+    _L.check(lib.kmcf_k_get_vectors(gpubuf.K_distributed, p["diag"], p["dinv"], p["rhs"], p["left"], p["right"]),
+             "kmcf_k_get_vectors")
+    out = {k: v[:n] for k, v in out.items()}
+    out["val"] = mat.get_values()
+    return out
+
+
+# --------------------------------------------------------------------------
+# dist_iterative surface
+# --------------------------------------------------------------------------
+
+class Distributed_matrix:
+    """Distributed_matrix + its Distributed_vector (dist_iterative/dist_objects.h:11-36, 69-233).
+    Construct from the rows of this rank in CSR with GLOBAL column indices (ctor 1, :158-167)."""
+
+    def __init__(self, kmc_comm, matrix_size, counts, displacements, col_indices_in, row_ptr_in, data_in):
+        self.lib = _L.load()
+        self.owned = True
+        h = C.c_void_p()
+        cnt, cntp = _ia(counts)
+        dsp, dspp = _ia(displacements)
+        rp, rpp = _ia(row_ptr_in)
+        ci, cip = _ia(col_indices_in)
+        dp = None
+        if data_in is not None:
+            dv, dp = _da(data_in)
+        _L.check(self.lib.kmcf_matrix_create_csr(kmc_comm.handle, int(matrix_size), cntp, dspp, rpp, cip, dp,
+                                                 C.byref(h)), "kmcf_matrix_create_csr")
+        self.handle = h
+
+    @classmethod
+    def from_handle(cls, handle):
+        self = cls.__new__(cls)
+        self.lib = _L.load()
+        self.handle = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self.owned = False
+        return self
+
+    def info(self):
+        inf = _L.MatrixInfo()
+        _L.check(self.lib.kmcf_matrix_info(self.handle, C.byref(inf)), "kmcf_matrix_info")
+        return {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    def neighbours(self):
+        """[(rank, nnz, cols_per_neighbour, rows_per_neighbour), ...] starting with self."""
+        out = []
+        for k in range(self.info()["number_of_neighbours"]):
+            r, nnz, nc, nr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            _L.check(self.lib.kmcf_matrix_neighbour(self.handle, k, C.byref(r), C.byref(nnz), C.byref(nc), None,
+                                                    C.byref(nr), None), "kmcf_matrix_neighbour")
+            cols = np.zeros(max(nc.value, 1), np.int32)
+            rows = np.zeros(max(nr.value, 1), np.int32)
+            _L.check(self.lib.kmcf_matrix_neighbour(self.handle, k, None, None, None,
+                                                    cols.ctypes.data_as(C.POINTER(C.c_int)), None,
+                                                    rows.ctypes.data_as(C.POINTER(C.c_int))), "kmcf_matrix_neighbour")
+            out.append(dict(rank=r.value, nnz=nnz.value, cols=cols[:nc.value], rows=rows[:nr.value]))
+        return out
+
+    def set_values(self, data):
+        dv, dp = _da(data)
+        _L.check(self.lib.kmcf_matrix_set_values(self.handle, dp), "kmcf_matrix_set_values")
+
+    def get_values(self):
+        out = np.zeros(max(self.info()["nnz"], 1))
+        _L.check(self.lib.kmcf_matrix_get_values(self.handle, out.ctypes.data_as(C.POINTER(C.c_double))),
+                 "kmcf_matrix_get_values")
+        return out[:self.info()["nnz"]]
+
+    def spmv(self, p, Ap):
+        """dspmv::gpu_packing_cam (dist_iterative/dist_spmv_gpu_packing.cpp:106-228)."""
+        _L.check(self.lib.kmcf_spmv(self.handle, _ptr(p), _ptr(Ap)), "kmcf_spmv")
+
+    def spmv_bench(self, reps, with_dot=True):
+        ms = C.c_float()
+        _L.check(self.lib.kmcf_spmv_bench(self.handle, int(reps), 1 if with_dot else 0, C.byref(ms)),
+                 "kmcf_spmv_bench")
+        return ms.value
+
+    def close(self):
+        if self.owned and self.handle:
+            self.lib.kmcf_matrix_destroy(self.handle)
+            self.handle = None
+
+
+def conjugate_gradient_jacobi(A_distributed, r_local_d, x_local_d, diag_inv_local_d, relative_tolerance,
+                              max_iterations, fixed_iters=0):
+    """iterative_solver::conjugate_gradient_jacobi (dist_iterative/dist_conjugate_gradient.cpp:149-276).
+    r_local_d: rhs in / residual out; x_local_d: start guess in / solution out."""
+    st = _L.SolveStats()
+    _L.check(A_distributed.lib.kmcf_pcg_jacobi(A_distributed.handle, _ptr(r_local_d), _ptr(x_local_d),
+                                               _ptr(diag_inv_local_d), float(relative_tolerance),
+                                               int(max_iterations), int(fixed_iters), C.byref(st)), "kmcf_pcg_jacobi")
+    return st.as_dict()
+
+
+def conjugate_gradient(A_distributed, r_local_d, x_local_d, relative_tolerance, max_iterations, fixed_iters=0):
+    """iterative_solver::conjugate_gradient (dist_conjugate_gradient.cpp:17-121): no preconditioner."""
+    return conjugate_gradient_jacobi(A_distributed, r_local_d, x_local_d, None, relative_tolerance, max_iterations,
+                                     fixed_iters)
+
+
+def solve_sparse_CG_Jacobi(A_distributed, d_rhs, d_x, tol=1e-14, max_iterations=50000):
+    """solve_sparse_CG_Jacobi (src/iterative_solvers_gpu.cu:716-887): A and rhs are scaled in place."""
+    st = _L.SolveStats()
+    _L.check(A_distributed.lib.kmcf_solve_sparse_CG_Jacobi(A_distributed.handle, _ptr(d_rhs), _ptr(d_x), float(tol),
+                                                           int(max_iterations), C.byref(st)),
+             "kmcf_solve_sparse_CG_Jacobi")
+    return st.as_dict()
+
+
+def pack_gpu(kmc_comm, packed_buffer, unpacked_buffer, indices, number_of_elements):
+    _L.check(_L.load().kmcf_pack(kmc_comm.handle, _ptr(packed_buffer), _ptr(unpacked_buffer), _ptr(indices),
+                                 int(number_of_elements)), "kmcf_pack")
+
+
+def unpack_gpu(kmc_comm, unpacked_buffer, packed_buffer, indices, number_of_elements):
+    _L.check(_L.load().kmcf_unpack(kmc_comm.handle, _ptr(unpacked_buffer), _ptr(packed_buffer), _ptr(indices),
+                                   int(number_of_elements)), "kmcf_unpack")
+
+
+def unpack_add(kmc_comm, unpacked_buffer, packed_buffer, indices, number_of_elements):
+    _L.check(_L.load().kmcf_unpack_add(kmc_comm.handle, _ptr(unpacked_buffer), _ptr(packed_buffer), _ptr(indices),
+                                       int(number_of_elements)), "kmcf_unpack_add")
+
+
+def elementwise_vector_vector(kmc_comm, array1, array2, result, size):
+    _L.check(_L.load().kmcf_elementwise_vector_vector(kmc_comm.handle, _ptr(array1), _ptr(array2), _ptr(result),
+                                                      int(size)), "kmcf_elementwise_vector_vector")

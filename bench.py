@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the field-solve hot path: Jacobi-PCG iterations/s on the (synthetic) 40 nm
+crossbar K matrix, row-partitioned over N GPUs, plus the CSR-SpMV roofline line and a CPU
+baseline.  Contract: see the task description / DESIGN.md "Measurement".
+
+    python bench.py --gpus 1 --steps 300 --warmup 30
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one PCG iteration (1 SpMV with fused p.Ap, the x/r/z update with fused r.z, the
+p update) on the assembled K matrix with the matrix and all vectors resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="40nm", choices=["40nm", "5nm", "small"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline iterations (0 = auto, ~10-30 s)")
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import kmcfield_amd as km
+    S = km.solvers
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        # gloo only carries the 128-byte RCCL bootstrap id, barriers and the max-over-ranks
+        # timing; the data path (halos, dot products) is RCCL inside libkmcfield
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    # ---- workload (identical on every rank; deterministic generator) ----------------------
+    t_gen = time.time()
+    if args.workload == "40nm":
+        d = km.structure.synth_crossbar_40nm()
+    elif args.workload == "small":
+        d = km.structure.synth_small(tiles=2)
+    else:
+        d = km.structure.load_device_5nm("init")
+    NL = d["N_contact"]
+    n_if = d["N"] - 2 * NL
+    comm = S.KMC_comm(n_if, d["N"] + 1, d["N"], d["N"], rank=rank, size=world, device=local_rank)
+    comm.connect(dist if world > 1 else None)
+    buf = S.GPUBuffers(d["N"], d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"], d["k"],
+                       d["lattice"], d["metals"], device=local_rank)
+    S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
+    S.initialize_sparsity_K(buf, d["pbc"], d["nn_dist"], NL, comm)
+    S.update_charge_gpu(buf.site_element, buf.site_charge, buf.neigh_idx, buf.N_, buf.nn_, buf.metal_types,
+                        buf.num_metal_types_, comm.counts_events, comm.displs_events, comm)
+    S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
+    info = mat.info()
+    vec = S.k_vectors(buf) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    t_setup = time.time() - t_gen
+    n_loc = info["rows_this_rank"]
+    nnz_loc = info["nnz"]
+    nnz_tot = torch.tensor([nnz_loc], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(nnz_tot)
+    nnz_tot = int(nnz_tot.item())
+
+    dev = torch.device("cuda", local_rank)
+    rhs_full = None
+
+    def fresh_vectors():
+        # rhs / dinv of the assembled system live in the K state; the generic CG entry takes
+        # caller-owned vectors like the reference (r_local_d, x_local_d, diag_inv_local_d)
+        kv = S.k_vectors(buf)
+        r = torch.as_tensor(kv["rhs"], device=dev).clone()
+        dinv = torch.as_tensor(kv["dinv"], device=dev)
+        x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+        return r, x, dinv
+
+    def barrier():
+        comm.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup + timed CG iterations -----------------------------------------------------
+    tol = 1e-14 * n_if
+    r, x, dinv = fresh_vectors()
+    if args.warmup > 0:
+        S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=args.warmup)
+    r, x, dinv = fresh_vectors()
+    barrier()
+    t0 = time.perf_counter()
+    st = S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert st["iterations"] == args.steps, st
+    el = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # ---- roofline of the dominant kernel: CSR SpMV (+ fused p.Ap) -------------------------
+    # HIP events on the library's compute stream (kmcf_spmv_bench), this rank's rows
+    mat.spmv_bench(5, True)
+    ms = mat.spmv_bench(args.spmv_reps, True)
+    spmv_us = ms * 1e3 / args.spmv_reps
+    alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc          # 12 B/nnz + 20 B/row
+    achieved = alg_bytes / (spmv_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "spmv_vec_kernel (CSR SpMV + fused p.Ap)", "us_per_launch": round(spmv_us, 2),
+                "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+    # ---- CPU baseline: the oracle's OpenMP PCG (same op sequence) on the host cores ---------
+    cpu = None
+    if vec is not None:
+        import kmcf_oracle as O
+        rp, col = S.k_pattern(buf, 0)
+        # the GPU box gives one GPU's share of the host: 16 cores (task rules); never oversubscribe
+        O.set_threads(min(16, os.cpu_count() or 1))
+        n_it = args.cpu_iters
+        tc = time.perf_counter()
+        O.pcg_jacobi_omp(rp, col, vec["val"], vec["rhs"], np.zeros(n_loc), vec["dinv"], tol, 10 ** 9, fixed_iters=5)
+        t5 = (time.perf_counter() - tc) / 6.0      # 5 iterations + the initial SpMV
+        if n_it <= 0:
+            n_it = int(max(5, min(5000, 15.0 / max(t5, 1e-6))))   # ~15 s of CPU work
+        tc = time.perf_counter()
+        O.pcg_jacobi_omp(rp, col, vec["val"], vec["rhs"], np.zeros(n_loc), vec["dinv"], tol, 10 ** 9, fixed_iters=n_it)
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(n_it / tc, 2), "unit": "iterations/s", "cores": O.omp_threads(), "kind": "port",
+               "sample": "%d fixed PCG iterations of the same matrix (oracle/kmcf_oracle.c orc_pcg_jacobi_omp, "
+                         "OpenMP, %.1f s)" % (n_it, tc)}
+
+    if rank == 0:
+        out = {
+            "metric": "cg_iterations_per_sec", "value": round(args.steps / elapsed, 2), "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": d["name"], "rows": n_if, "nnz": nnz_tot, "sites": d["N"],
+                       "partition": "1-D block rows x %d" % world, "solver": "jacobi-pcg fixed %d iterations" % args.steps,
+                       "halo_cols_rank0": info["halo_cols"], "neighbours_rank0": info["number_of_neighbours"],
+                       "setup_s": round(t_setup, 2), "device_ms_cg": round(st["ms_solve"], 3)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if args.workload == "5nm":
+            out["data"] = "reference 5nm_device (fixture)"
+        print(json.dumps(out))
+    buf.freeGPUmemory()
+    comm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

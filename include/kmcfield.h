@@ -1,0 +1,208 @@
+/*
+ * kmcfield.h -- C ABI of libkmcfield: MI355X-native (gfx950) field solve for
+ * DeviceKMC: on-device K-matrix assembly + distributed Jacobi-PCG over a 1-D
+ * row-partitioned CSR matrix.
+ *
+ * Every entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout).  All pointers named d_* are
+ * DEVICE pointers on the communicator's GPU, h_* are HOST pointers.  Values
+ * and vectors are double, indices / charges / ELEMENT are 32-bit int
+ * (ELEMENT is a plain enum, src/utils.h:37-44).
+ *
+ * Error convention: every function returns KMCF_OK (0) or a negative code and
+ * records a message retrievable with kmcf_last_error(); nothing calls exit()
+ * (the reference aborts: src/utils.h:145-154, dist_iterative/cudaerrchk.h:12-75).
+ * The C++ shim in kmcfield_compat.hpp restores abort-on-error for drop-in use.
+ *
+ * Process model: one process per GPU.  A kmcf_comm is this process's member of
+ * the solver group (the reference's MPI communicator comm_K, src/KMC_comm.h:
+ * 132-289).  Multi-rank groups exchange halos and dot products with RCCL.
+ */
+#ifndef KMCFIELD_H
+#define KMCFIELD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMCF_OK 0
+#define KMCF_ERR_ARG (-1)      /* bad argument / shape mismatch                */
+#define KMCF_ERR_HIP (-2)      /* a HIP runtime call failed                    */
+#define KMCF_ERR_COMM (-3)     /* RCCL failure or communicator not connected   */
+#define KMCF_ERR_STATE (-4)    /* call order violated (e.g. solve before assemble) */
+#define KMCF_ERR_NOMEM (-5)
+
+#define KMCF_UNIQUE_ID_BYTES 128
+
+typedef struct kmcf_comm kmcf_comm;     /* one rank of the solver group                  */
+typedef struct kmcf_matrix kmcf_matrix; /* Distributed_matrix + Distributed_vector       */
+typedef struct kmcf_kstate kmcf_kstate; /* what initialize_sparsity_K leaves in GPUBuffers */
+
+const char *kmcf_last_error(void);
+int kmcf_version(void);
+
+/* ---------------------------------------------------------------------- */
+/* Communicator (replaces MPI_Comm comm_K + select_gpu, src/kmc_main.cpp:   */
+/* 72-91, src/KMC_comm.h:225-289).                                          */
+/* ---------------------------------------------------------------------- */
+int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int rank);
+/* rank 0 calls kmcf_comm_unique_id, the host program distributes the 128 bytes
+ * (torch.distributed / MPI_Bcast), then every rank calls kmcf_comm_connect.
+ * A 1-rank group needs neither. */
+int kmcf_comm_unique_id(void *h_id128);
+int kmcf_comm_connect(kmcf_comm *c, const void *h_id128);
+int kmcf_comm_destroy(kmcf_comm *c);
+int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
+void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
+
+/* Block-row partition rule of the reference (src/KMC_comm.h:249-263,
+ * dist_iterative_test/utils.cpp:3-23). */
+int kmcf_partition(int nrows, int nranks, int *h_counts, int *h_displs);
+
+/* ---------------------------------------------------------------------- */
+/* Distributed CSR matrix (Distributed_matrix ctor 1, dist_iterative/        */
+/* dist_objects.h:158-167, dist_matrix.cpp:5-69; Distributed_vector          */
+/* dist_vector.cpp:3-42).  Input: the rows of this rank, GLOBAL column ids.  */
+/* The matrix must be structurally symmetric (dist_matrix.cpp:3).            */
+/* ---------------------------------------------------------------------- */
+int kmcf_matrix_create_csr(kmcf_comm *c, int matrix_size, const int *h_counts, const int *h_displs,
+                           const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                           kmcf_matrix **out);
+int kmcf_matrix_destroy(kmcf_matrix *m);
+
+typedef struct {
+    int matrix_size;          /* global rows                                        */
+    int rows_this_rank;
+    int64_t nnz;              /* of this rank, all blocks                           */
+    int number_of_neighbours; /* includes self (dist_objects.h:83)                  */
+    int halo_cols;            /* sum over k>=1 of nnz_cols_per_neighbour[k]         */
+    int send_rows;            /* sum over k>=1 of nnz_rows_per_neighbour[k]         */
+    int boundary_rows;        /* local rows that reference a halo column            */
+} kmcf_matrix_info_t;
+int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info);
+
+/* Halo lists for inspection (cols_per_neighbour / rows_per_neighbour,
+ * dist_matrix.cpp:390-487).  k in [0, number_of_neighbours); pass NULL to query
+ * sizes.  *neighbour_rank = neighbours[k]. */
+int kmcf_matrix_neighbour(const kmcf_matrix *m, int k, int *neighbour_rank, int *nnz_block,
+                          int *ncols, int *h_cols, int *nrows, int *h_rows);
+
+/* Overwrite the values (same order as the CSR given at creation). */
+int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val);
+/* Copy the values back (creation order). */
+int kmcf_matrix_get_values(const kmcf_matrix *m, double *h_val);
+
+/* Ap = A p, distributed: halo pack + exchange overlapped with the interior
+ * rows, then boundary rows (dspmv::gpu_packing_cam, dist_iterative/
+ * dist_spmv_gpu_packing.cpp:106-228).  d_p, d_Ap: rows_this_rank doubles.
+ * Synchronous (returns after the result is visible). */
+int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap);
+
+/* Timing helper for the roofline line: runs `reps` SpMVs (with_dot != 0: the
+ * CG variant with the fused p.Ap partial) on the compute stream bracketed by HIP
+ * events on that stream; *ms_total receives the elapsed time. */
+int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms_total);
+
+typedef struct {
+    int iterations;       /* CG iterations executed (reference prints K = iterations+1) */
+    int converged;        /* 1 if the stopping rule was met                             */
+    double relres;        /* sqrt(rz/bb), dist_conjugate_gradient.cpp:273                */
+    double bb;            /* ||b||^2 (all ranks)                                        */
+    double rz;            /* last r.z                                                   */
+    float ms_solve;       /* device time of the CG loop (HIP events, compute stream)    */
+    float ms_assembly;    /* device time of the assembly kernels (K solve only)         */
+} kmcf_solve_stats_t;
+
+/* Jacobi-PCG (iterative_solver::conjugate_gradient_jacobi, dist_iterative/
+ * dist_conjugate_gradient.cpp:149-276).  d_r: rhs in, residual out; d_x: start
+ * guess in, solution out; d_diag_inv: 1/diag (NULL = unpreconditioned CG,
+ * conjugate_gradient :17-121).  Stop when r.z/(b.b) <= tol^2 or after max_it
+ * iterations; fixed_iters > 0 runs exactly that many (bench mode). */
+int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const double *d_diag_inv,
+                    double relative_tolerance, int max_iterations, int fixed_iters,
+                    kmcf_solve_stats_t *stats);
+
+/* Single-GPU symmetric-scaled CG (solve_sparse_CG_Jacobi, src/
+ * iterative_solvers_gpu.cu:716-887): solves D^-1/2 A D^-1/2 y = D^-1/2 b with
+ * an absolute stop ||r||^2 <= tol^2 (tol 1e-14, max 50000 there); A values and
+ * rhs are scaled IN PLACE like the reference.  Requires a 1-rank matrix. */
+int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double *d_x,
+                                double tol, int max_iterations, kmcf_solve_stats_t *stats);
+
+/* Small vector kernels of dist_iterative/utils_cg.cu (:4-111, :323-336). */
+int kmcf_pack(kmcf_comm *c, double *d_packed, const double *d_unpacked, const int *d_indices, int n);
+int kmcf_unpack(kmcf_comm *c, double *d_unpacked, const double *d_packed, const int *d_indices, int n);
+int kmcf_unpack_add(kmcf_comm *c, double *d_unpacked, const double *d_packed, const int *d_indices, int n);
+int kmcf_elementwise_vector_vector(kmcf_comm *c, const double *d_a, const double *d_b, double *d_out, int n);
+
+/* ---------------------------------------------------------------------- */
+/* K path                                                                    */
+/* ---------------------------------------------------------------------- */
+
+/* initialize_sparsity_K (src/iterative_solvers_gpu.cu:262-488): pattern of K
+ * restricted to the interface sites [N_contact, N - N_contact) for the rows of
+ * this rank + left/right contact patterns, built with a cell list instead of
+ * the reference's O(n_loc*N) scan.  d_x/d_y/d_z: N site coordinates;
+ * h_lattice[3]; counts/displs: row partition of the N - 2*N_contact interface
+ * rows (kmc_comm.counts_K / displs_K). */
+int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const double *d_y, const double *d_z,
+                               const double *h_lattice, int N, int pbc, double nn_dist, int N_contact,
+                               const int *h_counts, const int *h_displs, kmcf_kstate **out);
+int kmcf_kstate_destroy(kmcf_kstate *k);
+kmcf_matrix *kmcf_kstate_matrix(kmcf_kstate *k);   /* gpubuf.K_distributed */
+
+/* Pattern export for tests (global interface column ids, ascending per row);
+ * which: 0 = K rows of this rank, 1 = left contact block, 2 = right contact
+ * block.  Pass h_col = NULL to query *nnz. */
+int kmcf_kstate_pattern(const kmcf_kstate *k, int which, int *h_row_ptr, int *h_col, int64_t *nnz);
+
+/* update_charge_gpu (src/potential_solver_gpu.cu:12-85): writes the charges of
+ * the rows [displ[rank], displ[rank]+count[rank]) and all-gathers them. */
+int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *d_site_charge, const int *d_neigh_idx,
+                       int N, int nn, const int *d_metals, int num_metals,
+                       const int *h_count, const int *h_displ);
+
+/* K value assembly only (the first half of background_potential_gpu_sparse,
+ * src/potential_solver_gpu.cu:888-1042 with kernels :246-285, :323-367,
+ * :438-454, :774-830): fills the CSR values, diagonal, 1/diag and rhs. */
+int kmcf_k_assemble(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                    const int *d_metals, int num_metals, double Vd, double high_G, double low_G);
+/* Copies of the assembled per-row vectors (rows_this_rank each; NULL to skip). */
+int kmcf_k_get_vectors(const kmcf_kstate *k, double *h_diag, double *h_dinv, double *h_rhs,
+                       double *h_left, double *h_right);
+
+/* background_potential_gpu_sparse (src/potential_solver_gpu.cu:846-1128):
+ * assembly + PCG (tol 1e-14*N_interface, max_it 10000, :885-886), solution
+ * written in place into d_site_potential_boundary[N_left + displ ...] whose
+ * previous content is the initial guess. */
+int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                                     const int *d_metals, int num_metals,
+                                     double *d_site_potential_boundary,
+                                     int N, int N_left_tot, int N_right_tot, double Vd,
+                                     double high_G, double low_G, kmcf_solve_stats_t *stats);
+
+/* The MPI_Gatherv of the solution (src/kmc_main.cpp:367-384) + the two
+ * MPI_Bcast + sum_AB_into_A of sum_and_gather_potential
+ * (src/potential_solver_gpu.cu:1130-1151): replicates the interface solution
+ * on every rank and does site_potential_charge += site_potential_boundary. */
+int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_potential_boundary,
+                                  double *d_site_potential_charge, int N, int num_atoms_first_layer);
+
+/* update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70). */
+int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,
+                                   double a_coeff, double b_coeff, double number_steps,
+                                   double C_thermal, double small_step);
+
+/* Site neighbour index list (compute_neighbor_list, src/neighbor_lists_gpu.cu:
+ * 55-77, 252-292): nn slots per site, -1 padded, ascending j.  Cell list
+ * instead of the O(N^2) scan.  d_neigh_idx: count*nn ints. */
+int kmcf_neighbor_list(kmcf_comm *c, const double *d_x, const double *d_y, const double *d_z, int N,
+                       double nn_dist, int nn, int count, int displ, int *d_neigh_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMCFIELD_H */

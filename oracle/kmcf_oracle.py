@@ -190,6 +190,10 @@ def omp_threads():
     return lib().orc_omp_threads()
 
 
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 def halo_lists(row_ptr, col, P, rank):
     """Neighbour list + halo index lists of `rank` (dist_matrix.cpp:237-487)."""
     n = len(row_ptr) - 1

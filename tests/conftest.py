@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; built on demand with gcc)."""
+    import kmcf_oracle
+    kmcf_oracle.lib()
+    return kmcf_oracle
+
+
+@pytest.fixture(scope="session")
+def km():
+    import kmcfield_amd
+    if not os.path.exists(kmcfield_amd.lib.LIB_PATH):
+        kmcfield_amd.build()
+    return kmcfield_amd
+
+
+@pytest.fixture(scope="session")
+def dev5(km):
+    return km.structure.load_device_5nm("init")
+
+
+@pytest.fixture(scope="session")
+def ref5(oracle, dev5):
+    """Oracle results on the 5 nm device (pattern, neighbour list, charges, K system, cold PCG)."""
+    import numpy as np
+    d = dev5
+    NL = d["N_contact"]
+    ks = oracle.KSystem(d["xyz"], d["lattice"], d["pbc"], d["nn_dist"], NL, NL)
+    nl = oracle.neighbor_list(d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], d["nn_dist"], 52)
+    charge = oracle.update_charge(d["element"], np.zeros(d["N"], np.int32), nl, d["metals"])
+    A = oracle.assemble_K(ks, d["element"], charge, d["metals"], d["high_G"], d["low_G"], d["Vd"])
+    tol = 1e-14 * ks.n
+    x, it, rel = oracle.pcg_jacobi(ks.row_ptr, ks.col, A["val"], A["rhs"], np.zeros(ks.n), A["dinv"], tol, 10000)
+    return dict(ks=ks, neigh=nl, charge=charge, A=A, x=x, iters=it, relres=rel, tol=tol)

@@ -188,7 +188,7 @@ def test_background_potential_end_to_end(km, sys5, ref5):
     v = buf.site_potential_boundary.cpu().numpy()
     assert np.all(v[:NL] == 0) and np.all(v[-NL:] == 0)        # contacts are not written
     assert np.abs(v[NL:-NL] - ref5["x"]).max() <= 5e-4
-    assert v.min() >= -2.5 - 1e-9 and v.max() <= 2.5 + 1e-9     # |V| <= Vd/2
+    assert v.min() >= -2.5 - 1e-7 and v.max() <= 2.5 + 1e-7     # |V| <= Vd/2 up to the CG tolerance
     # warm start: already converged -> the loop body never runs (reference: 0.67 ms steps 2-6)
     st2 = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                             d["nn_dist"], len(d["metals"]), 1)

@@ -111,7 +111,13 @@ struct kmcf_matrix {
     // SpMV launch plan
     int spmv_grid = 0;                 // interior pass grid (= number of pAp partials it writes)
     int spmv_grid_b = 0;               // boundary pass grid
-    int spmv_lpr = 16;                 // lanes per row
+    int spmv_lpr = 16;                 // lanes per row (vec kernel)
+    int spmv_kind = 0;                 // 0: vec<LPR>, 1: stream (nnz-chunked, LDS row reduction)
+    int spmv_u = 8;                    // stream: nnz per thread per chunk
+    int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction
+    int n_chunks = 0;
+    int *d_chunk_row = nullptr;        // stream: first row of each chunk (n_chunks + 1)
+    std::vector<int> h_row_ptr;        // host copy of row_ptr (launch planning)
 };
 
 struct kmcf_kstate {

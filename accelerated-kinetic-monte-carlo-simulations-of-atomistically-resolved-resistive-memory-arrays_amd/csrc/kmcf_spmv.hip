@@ -5,12 +5,24 @@
 // 20 B/row (row_ptr, x once, y once); x gathers are served by L2/Infinity Cache.
 // No MFMA: 2 flop per 12 streamed bytes.
 //
-// Kernel "vec<LPR>": LPR lanes cooperate on one row (64/LPR rows per wavefront),
-// strided walk of the row so a wavefront touches one contiguous nnz span per
-// step, wave-shuffle (DPP) reduction, and the p.Ap dot product of CG fused in
-// (one partial per block, reduced deterministically by the consumer kernel).
-// Block -> row mapping is XCD-aware: blocks with equal blockIdx % 8 (same XCD, hence
-// same L2) walk one contiguous eighth of the rows, so each L2 holds one x window.
+// Two kernels, chosen per matrix in kmcf_spmv_plan():
+//
+//  "stream" (default for short rows, e.g. K: 4..53 nnz/row): the nnz range is cut
+//    into chunks of whole rows (<= 256*U nnz).  A 256-thread block streams a chunk's
+//    values and columns with fully coalesced loads that do not depend on row_ptr (U
+//    independent loads per lane in flight -> memory-level parallelism instead of the
+//    row_ptr -> col -> x dependency chain per row), gathers x, parks the products in
+//    LDS and then reduces them per row out of LDS.
+//  "vec<LPR>": LPR lanes cooperate on one row (64/LPR rows per wavefront), wave-shuffle
+//    reduction.  Used for the boundary-row pass (row list) and for matrices with rows
+//    longer than a chunk.
+//
+// Both fuse the p.Ap dot product of CG (one partial per block, reduced in a fixed order
+// by the consumer kernel) and map blocks to rows XCD-aware: blocks with equal
+// blockIdx % 8 (same XCD, same L2) walk one contiguous eighth of the matrix, so each L2
+// holds one window of x.
+#include <cstdlib>
+
 #include "kmcf_internal.hpp"
 
 namespace {
@@ -35,6 +47,71 @@ __device__ __forceinline__ double block_sum_256(double v, double *lds4)
     return t;
 }
 
+// ------------------------------------------------------------------ stream kernel
+template <int U, int LPR2, bool DOT, bool SKIP_BOUNDARY>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
+    int n_chunks, const int *__restrict__ chunk_row, const int *__restrict__ row_ptr,
+    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const unsigned char *__restrict__ is_boundary,
+    double *__restrict__ part, const kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double prod[KMCF_BLOCK * U];
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Cx = (n_chunks + 7) >> 3;  // chunks per XCD
+    double dot = 0.0;
+    for (int g = bi; g < Cx; g += nb8) {
+        const int c = xcd * Cx + g;
+        if (c >= n_chunks) break;        // block-uniform
+        const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+        const int base = row_ptr[r0];
+        const int cnt = row_ptr[r1] - base;
+        // phase 1: stream values/columns, gather x, park products
+        double v[U];
+        int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * KMCF_BLOCK + tid;
+            const bool in = i < cnt;
+            v[u] = in ? val[base + i] : 0.0;
+            ci[u] = in ? col[base + i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * KMCF_BLOCK + tid;
+            if (i < cnt) prod[i] = v[u] * x[ci[u]];
+        }
+        __syncthreads();
+        // phase 2: per-row sums out of LDS, LPR2 lanes per row
+        constexpr int RPP = KMCF_BLOCK / LPR2;  // rows per pass
+        const int lane = tid % LPR2;
+        const int nrows = r1 - r0;
+        const int passes = (nrows + RPP - 1) / RPP;
+        for (int ps = 0; ps < passes; ++ps) {
+            const int rr = r0 + ps * RPP + tid / LPR2;
+            const bool valid = rr < r1;
+            double s = 0.0;
+            if (valid) {
+                const int b = row_ptr[rr] - base, e = row_ptr[rr + 1] - base;
+                for (int j = b + lane; j < e; j += LPR2) s += prod[j];
+            }
+            if (LPR2 > 1) s = wave_sum_width(s, LPR2);
+            if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
+                y[rr] = s;
+                if (DOT) dot += x[rr] * s;
+            }
+        }
+        __syncthreads();
+    }
+    if (DOT) {
+        double t = block_sum_256(dot, lds4);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ vector kernel
 template <int LPR, bool DOT, bool SKIP_BOUNDARY, bool ROW_LIST>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_kernel(
     int n_rows, const int *__restrict__ row_ptr, const int *__restrict__ col,
@@ -113,6 +190,9 @@ int grid_for(int64_t work_items, int per_block)
     return (int)((g + 7) / 8 * 8);
 }
 
+#define KMCF_VEC_ARGS(nrows, isb, rl, part) \
+    nrows, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, isb, rl, part, m->d_S, chk
+
 template <int LPR>
 void launch_vec(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_pass)
 {
@@ -123,34 +203,28 @@ void launch_vec(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_
         const bool skipb = (m->n_halo > 0);
         if (with_dot) {
             if (skipb)
-                spmv_vec_kernel<LPR, true, true, false><<<grid, KMCF_BLOCK, 0, st>>>(
-                    m->n_loc, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, m->d_is_boundary, nullptr, m->d_part_a, m->d_S, chk);
+                spmv_vec_kernel<LPR, true, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, m->d_is_boundary, nullptr, m->d_part_a));
             else
-                spmv_vec_kernel<LPR, true, false, false><<<grid, KMCF_BLOCK, 0, st>>>(
-                    m->n_loc, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, nullptr, nullptr, m->d_part_a, m->d_S, chk);
+                spmv_vec_kernel<LPR, true, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, nullptr, nullptr, m->d_part_a));
         } else {
             if (skipb)
-                spmv_vec_kernel<LPR, false, true, false><<<grid, KMCF_BLOCK, 0, st>>>(
-                    m->n_loc, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, m->d_is_boundary, nullptr, nullptr, m->d_S, chk);
+                spmv_vec_kernel<LPR, false, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, m->d_is_boundary, nullptr, nullptr));
             else
-                spmv_vec_kernel<LPR, false, false, false><<<grid, KMCF_BLOCK, 0, st>>>(
-                    m->n_loc, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, nullptr, nullptr, nullptr, m->d_S, chk);
+                spmv_vec_kernel<LPR, false, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, nullptr, nullptr, nullptr));
         }
     } else {
         const int grid = m->spmv_grid_b;
         // partials of the boundary pass live behind the interior ones
         if (with_dot)
             spmv_vec_kernel<LPR, true, false, true><<<grid, KMCF_BLOCK, 0, st>>>(
-                m->n_boundary_rows, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, nullptr, m->d_boundary_rows,
-                m->d_part_a + KMCF_MAX_PARTIALS, m->d_S, chk);
+                KMCF_VEC_ARGS(m->n_boundary_rows, nullptr, m->d_boundary_rows, m->d_part_a + KMCF_MAX_PARTIALS));
         else
             spmv_vec_kernel<LPR, false, false, true><<<grid, KMCF_BLOCK, 0, st>>>(
-                m->n_boundary_rows, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, nullptr, m->d_boundary_rows,
-                nullptr, m->d_S, chk);
+                KMCF_VEC_ARGS(m->n_boundary_rows, nullptr, m->d_boundary_rows, nullptr));
     }
 }
 
-void launch_any(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_pass)
+void launch_vec_any(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_pass)
 {
     switch (m->spmv_lpr) {
         case 4: launch_vec<4>(m, with_dot, skip_if_done, boundary_pass); break;
@@ -161,28 +235,96 @@ void launch_any(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_
     }
 }
 
+#define KMCF_STREAM_ARGS(isb, part) \
+    m->n_chunks, m->d_chunk_row, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, isb, part, m->d_S, chk
+
+template <int U, int LPR2>
+void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+{
+    hipStream_t st = m->comm->stream;
+    const int chk = skip_if_done ? 1 : 0;
+    const int grid = m->spmv_grid;
+    const bool skipb = (m->n_halo > 0);
+    if (with_dot) {
+        if (skipb) spmv_stream_kernel<U, LPR2, true, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, m->d_part_a));
+        else spmv_stream_kernel<U, LPR2, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, m->d_part_a));
+    } else {
+        if (skipb) spmv_stream_kernel<U, LPR2, false, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, nullptr));
+        else spmv_stream_kernel<U, LPR2, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, nullptr));
+    }
+}
+
+void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+{
+    if (m->spmv_kind == 1) {
+        const int key = m->spmv_u * 100 + m->spmv_lpr2;
+        switch (key) {
+            case 401: launch_stream<4, 1>(m, with_dot, skip_if_done); break;
+            case 404: launch_stream<4, 4>(m, with_dot, skip_if_done); break;
+            case 801: launch_stream<8, 1>(m, with_dot, skip_if_done); break;
+            case 808: launch_stream<8, 8>(m, with_dot, skip_if_done); break;
+            case 1604: launch_stream<16, 4>(m, with_dot, skip_if_done); break;
+            default: launch_stream<8, 4>(m, with_dot, skip_if_done); break;
+        }
+    } else {
+        launch_vec_any(m, with_dot, skip_if_done, false);
+    }
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 }  // namespace
 
 int kmcf_spmv_plan(kmcf_matrix *m)
 {
-    // lanes per row from the mean row length (K rows hold 4..53 entries, mean 25.8)
-    double mean = m->n_loc > 0 ? double(m->nnz) / m->n_loc : 0.0;
+    // vec kernel: lanes per row from the mean row length (K rows hold 4..53 entries, mean 25.8)
+    const double mean = m->n_loc > 0 ? double(m->nnz) / m->n_loc : 0.0;
     int lpr = 4;
     while (lpr < 64 && lpr * 2 <= mean) lpr *= 2;  // 25.8 -> 16
-    if (const char *e = getenv("KMCF_SPMV_LPR")) {
-        int v = atoi(e);
+    {
+        int v = env_int("KMCF_SPMV_LPR", 0);
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lpr = v;
     }
     m->spmv_lpr = lpr;
-    m->spmv_grid = grid_for(m->n_loc, KMCF_BLOCK / lpr);
     m->spmv_grid_b = m->n_boundary_rows > 0 ? grid_for(m->n_boundary_rows, KMCF_BLOCK / lpr) : 0;
-    // zero the partial slots once: grids never shrink below what a consumer reads
+
+    // stream kernel: chunks of whole rows with at most 256*U nnz
+    int u = env_int("KMCF_SPMV_U", 8);
+    if (u != 4 && u != 8 && u != 16) u = 8;
+    m->spmv_u = u;
+    m->spmv_lpr2 = env_int("KMCF_SPMV_LPR2", 4);
+    const int cap = KMCF_BLOCK * u;
+    int kind = env_int("KMCF_SPMV_KIND", 1);
+    std::vector<int> chunk_row;
+    if (kind == 1) {
+        const std::vector<int> &rp = m->h_row_ptr;
+        chunk_row.push_back(0);
+        int r = 0;
+        while (r < m->n_loc) {
+            const int start = rp[r];
+            int e = r;
+            while (e < m->n_loc && rp[e + 1] - start <= cap) ++e;
+            if (e == r) { kind = 0; break; }   // a single row exceeds a chunk: vector kernel
+            chunk_row.push_back(e);
+            r = e;
+        }
+        if (m->n_loc == 0) kind = 0;
+    }
+    m->spmv_kind = kind;
+    if (kind == 1) {
+        m->n_chunks = (int)chunk_row.size() - 1;
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_chunk_row), chunk_row.size() * sizeof(int)));
+        KMCF_HIP(hipMemcpy(m->d_chunk_row, chunk_row.data(), chunk_row.size() * sizeof(int), hipMemcpyHostToDevice));
+        m->spmv_grid = grid_for(m->n_chunks, 1);
+    } else {
+        m->spmv_grid = grid_for(m->n_loc, KMCF_BLOCK / lpr);
+    }
     return KMCF_OK;
 }
-
-// Number of pAp partials a consumer has to reduce (interior grid + boundary grid slots).
-// Partials are laid out [0, KMCF_MAX_PARTIALS) interior, [KMCF_MAX_PARTIALS, 2x) boundary;
-// unused slots stay zero (allocated zeroed, grids are fixed per matrix).
 
 int kmcf_halo_exchange_begin(kmcf_matrix *m)
 {
@@ -211,12 +353,12 @@ int kmcf_halo_exchange_end(kmcf_matrix *m)
 int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     KMCF_TRY(kmcf_halo_exchange_begin(m));
-    launch_any(m, with_dot, skip_if_done, false);
+    launch_interior(m, with_dot, skip_if_done);
     KMCF_HIP(hipGetLastError());
     if (m->n_halo > 0) {
         KMCF_TRY(kmcf_halo_exchange_end(m));
         if (m->n_boundary_rows > 0) {
-            launch_any(m, with_dot, skip_if_done, true);
+            launch_vec_any(m, with_dot, skip_if_done, true);
             KMCF_HIP(hipGetLastError());
         }
     }
@@ -248,6 +390,16 @@ extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms
     KMCF_HIP(hipEventSynchronize(c->ev_t1));
     KMCF_HIP(hipEventElapsedTime(ms_total, c->ev_t0, c->ev_t1));
     return KMCF_OK;
+}
+
+// Re-plan the SpMV of an existing matrix from the KMCF_SPMV_* environment (tuning aid).
+extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
+{
+    KMCF_CHECK(m && m->d_val, KMCF_ERR_ARG, "kmcf_spmv_replan: bad matrix");
+    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_HIP(hipStreamSynchronize(m->comm->stream));
+    if (m->d_chunk_row) { hipFree(m->d_chunk_row); m->d_chunk_row = nullptr; }
+    return kmcf_spmv_plan(m);
 }
 
 extern "C" int kmcf_pack(kmcf_comm *c, double *d_packed, const double *d_unpacked, const int *d_indices, int n)

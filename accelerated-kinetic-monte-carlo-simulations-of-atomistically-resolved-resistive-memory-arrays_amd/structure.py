@@ -132,6 +132,14 @@ def synth_crossbar_40nm(tiles=8, fill=0.52, n_lines=2, vacancy_fraction=0.05, se
         mid = mid[np.lexsort((xyz[mid, 0], xyz[mid, 2], xyz[mid, 1]))]   # y, then z, then x
         left = left[np.lexsort((xyz[left, 2], xyz[left, 1]))]
         right = right[np.lexsort((xyz[right, 2], xyz[right, 1]))]
+    elif order.startswith("brick"):
+        # experiment: space-filling "brick" order (brick edge in Angstrom after the colon)
+        edge = float(order.split(":")[1]) if ":" in order else 7.7
+        b = np.floor(xyz[mid] / edge).astype(np.int64)
+        key = (b[:, 1] * 100000 + b[:, 2]) * 100000 + b[:, 0]
+        mid = mid[np.lexsort((xyz[mid, 0], xyz[mid, 2], xyz[mid, 1], key))]
+        left = left[np.lexsort((xyz[left, 2], xyz[left, 1]))]
+        right = right[np.lexsort((xyz[right, 2], xyz[right, 1]))]
     elif order != "original":
         raise ValueError(order)
     assert len(left) == len(right), (len(left), len(right))

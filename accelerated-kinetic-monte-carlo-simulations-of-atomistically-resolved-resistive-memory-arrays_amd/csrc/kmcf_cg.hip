@@ -183,7 +183,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     hipStream_t st = c->stream;
     const int n = m->n_loc;
     const int vg = vec_grid(n);
-    const bool multi = c->nranks > 1;
+    const bool multi = c->nranks > 1 || c->force_collectives;
     kmcf_scalars *S = m->d_S;
     const double tol2 = tol * tol;
     const int check_tol = fixed_iters > 0 ? 0 : (absolute ? 2 : 1);

@@ -133,25 +133,40 @@ extern "C" int kmcf_comm_unique_id(void *h_id128)
 {
     KMCF_CHECK(h_id128, KMCF_ERR_ARG, "kmcf_comm_unique_id: null buffer");
     KMCF_TRY(load_rccl());
-    static_assert(sizeof(ncclUniqueId) == KMCF_UNIQUE_ID_BYTES, "unique id size");
-    ncclUniqueId id;
-    KMCF_NCCL(g_rccl.GetUniqueId(&id));
-    memcpy(h_id128, &id, sizeof(id));
+    // two RCCL communicators: [0] halo send/recv on the comm stream, [1] reductions and gathers on
+    // the compute stream -- one communicator must not be driven from two streams concurrently
+    static_assert(2 * sizeof(ncclUniqueId) == KMCF_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id[2];
+    KMCF_NCCL(g_rccl.GetUniqueId(&id[0]));
+    KMCF_NCCL(g_rccl.GetUniqueId(&id[1]));
+    memcpy(h_id128, id, sizeof(id));
     return KMCF_OK;
 }
 
 extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
 {
     KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_connect: null comm");
-    if (c->nranks == 1) { c->connected = true; return KMCF_OK; }
-    KMCF_CHECK(h_id128, KMCF_ERR_ARG, "kmcf_comm_connect: null id");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_comm_connect: host-only communicator");
+    // KMCF_FORCE_COMM=1 (test aid): a 1-rank group also creates its RCCL communicators and runs
+    // every collective of the multi-rank code path (all-reduce of the dots, gathers)
+    const bool force = getenv("KMCF_FORCE_COMM") != nullptr;
+    if (c->nranks == 1 && !force) { c->connected = true; return KMCF_OK; }
     KMCF_TRY(load_rccl());
     KMCF_HIP(hipSetDevice(c->device));
-    ncclUniqueId id;
-    memcpy(&id, h_id128, sizeof(id));
+    ncclUniqueId id[2];
+    if (c->nranks == 1) {
+        KMCF_NCCL(g_rccl.GetUniqueId(&id[0]));
+        KMCF_NCCL(g_rccl.GetUniqueId(&id[1]));
+    } else {
+        KMCF_CHECK(h_id128, KMCF_ERR_ARG, "kmcf_comm_connect: null id");
+        memcpy(id, h_id128, sizeof(id));
+    }
     ncclComm_t comm;
-    KMCF_NCCL(g_rccl.CommInitRank(&comm, c->nranks, id, c->rank));
+    KMCF_NCCL(g_rccl.CommInitRank(&comm, c->nranks, id[0], c->rank));
     c->nccl = comm;
+    KMCF_NCCL(g_rccl.CommInitRank(&comm, c->nranks, id[1], c->rank));
+    c->nccl_red = comm;
+    c->force_collectives = force;
     c->connected = true;
     return KMCF_OK;
 }
@@ -164,6 +179,7 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
     if (c->nccl) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
+    if (c->nccl_red) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_red));
     if (c->ev_packed) hipEventDestroy(c->ev_packed);
     if (c->ev_halo) hipEventDestroy(c->ev_halo);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
@@ -189,10 +205,10 @@ extern "C" void *kmcf_comm_stream(kmcf_comm *c) { return c ? static_cast<void *>
 // Sum `count` doubles in place over all ranks, on the compute stream, device resident.
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 {
-    if (c->nranks == 1) return KMCF_OK;
-    KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
+    if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
+    KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
     KMCF_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum,
-                               static_cast<ncclComm_t>(c->nccl), c->stream));
+                               static_cast<ncclComm_t>(c->nccl_red), c->stream));
     return KMCF_OK;
 }
 
@@ -222,9 +238,9 @@ int kmcf_comm_send_recv_halo(kmcf_matrix *m)
 template <typename T>
 static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int *displs, ncclDataType_t dt)
 {
-    if (c->nranks == 1) return KMCF_OK;
-    KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
-    ncclComm_t comm = static_cast<ncclComm_t>(c->nccl);
+    if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
+    KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
+    ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_red);
     KMCF_NCCL(g_rccl.GroupStart());
     for (int q = 0; q < c->nranks; ++q)
         if (counts[q] > 0)

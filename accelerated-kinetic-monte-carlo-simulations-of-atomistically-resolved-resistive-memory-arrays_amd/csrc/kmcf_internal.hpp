@@ -61,7 +61,9 @@ struct kmcf_comm {
     hipEvent_t ev_packed = nullptr;     // compute -> comm
     hipEvent_t ev_halo = nullptr;       // comm -> compute
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    void *nccl = nullptr;               // ncclComm_t
+    void *nccl = nullptr;               // ncclComm_t: halo send/recv (comm stream)
+    void *nccl_red = nullptr;           // ncclComm_t: all-reduce / gathers (compute stream)
+    bool force_collectives = false;     // KMCF_FORCE_COMM: 1-rank group still runs the collectives
     bool connected = false;
     int *h_pinned = nullptr;            // 16 ints pinned host (done/iters read-back)
 };

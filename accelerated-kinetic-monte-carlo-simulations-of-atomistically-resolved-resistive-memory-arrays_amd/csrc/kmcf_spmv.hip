@@ -62,9 +62,12 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
     const int Cx = (n_chunks + 7) >> 3;  // chunks per XCD
     double dot = 0.0;
-    for (int g = bi; g < Cx; g += nb8) {
+    for (int g0 = bi; g0 < Cx + nb8; g0 += nb8) {
+        // check_done bit 1 (lab): co-resident blocks of a CU (assumed bi % 32 == CU) take adjacent chunks
+        int g = g0;
+        if ((check_done & 2) && nb8 == 256) g = (g0 & ~255) + ((bi & 31) << 3) + (bi >> 5);
         const int c = xcd * Cx + g;
-        if (c >= n_chunks) break;        // block-uniform
+        if (g >= Cx || c >= n_chunks) { if (check_done & 2) continue; else break; }   // block-uniform
         const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
         const int base = row_ptr[r0];
         const int cnt = row_ptr[r1] - base;
@@ -75,8 +78,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
         for (int u = 0; u < U; ++u) {
             const int i = u * KMCF_BLOCK + tid;
             const bool in = i < cnt;
-            v[u] = in ? val[base + i] : 0.0;
-            ci[u] = in ? col[base + i] : 0;
+            // streamed once: nontemporal loads keep the vector L1 for the x lines
+            v[u] = in ? __builtin_nontemporal_load(val + base + i) : 0.0;
+            ci[u] = in ? __builtin_nontemporal_load(col + base + i) : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -242,7 +246,7 @@ template <int U, int LPR2>
 void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     hipStream_t st = m->comm->stream;
-    const int chk = skip_if_done ? 1 : 0;
+    const int chk = (skip_if_done ? 1 : 0) | (getenv("KMCF_SPMV_MAP") ? 2 : 0);
     const int grid = m->spmv_grid;
     const bool skipb = (m->n_halo > 0);
     if (with_dot) {

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmcfield.so")
 
-KMCF_UNIQUE_ID_BYTES = 128
+KMCF_UNIQUE_ID_BYTES = 256
 
 
 class KmcfError(RuntimeError):

@@ -35,7 +35,7 @@ extern "C" {
 #define KMCF_ERR_STATE (-4)    /* call order violated (e.g. solve before assemble) */
 #define KMCF_ERR_NOMEM (-5)
 
-#define KMCF_UNIQUE_ID_BYTES 128
+#define KMCF_UNIQUE_ID_BYTES 256   /* two RCCL unique ids: halo communicator + reduction communicator */
 
 typedef struct kmcf_comm kmcf_comm;     /* one rank of the solver group                  */
 typedef struct kmcf_matrix kmcf_matrix; /* Distributed_matrix + Distributed_vector       */
@@ -49,11 +49,11 @@ int kmcf_version(void);
 /* 72-91, src/KMC_comm.h:225-289).                                          */
 /* ---------------------------------------------------------------------- */
 int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int rank);
-/* rank 0 calls kmcf_comm_unique_id, the host program distributes the 128 bytes
+/* rank 0 calls kmcf_comm_unique_id, the host program distributes the KMCF_UNIQUE_ID_BYTES
  * (torch.distributed / MPI_Bcast), then every rank calls kmcf_comm_connect.
  * A 1-rank group needs neither. */
-int kmcf_comm_unique_id(void *h_id128);
-int kmcf_comm_connect(kmcf_comm *c, const void *h_id128);
+int kmcf_comm_unique_id(void *h_id /* KMCF_UNIQUE_ID_BYTES */);
+int kmcf_comm_connect(kmcf_comm *c, const void *h_id /* KMCF_UNIQUE_ID_BYTES */);
 int kmcf_comm_destroy(kmcf_comm *c);
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */

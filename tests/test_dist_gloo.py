@@ -59,9 +59,9 @@ def _worker(rank, world, port, q):
         for peer, lst in recv.items():
             ok &= gathered[peer]["send"].get(rank) == lst
         # the unique-id broadcast path of KMC_comm.connect (bytes tensor over the process group)
-        t = torch.arange(128, dtype=torch.uint8) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
+        t = torch.arange(256, dtype=torch.int16).to(torch.uint8) if rank == 0 else torch.zeros(256, dtype=torch.uint8)
         dist.broadcast(t, src=0)
-        ok &= t.tolist() == list(range(128))
+        ok &= t.tolist() == [i % 256 for i in range(256)]
         # distributed solution emulation: every rank runs the oracle's P-rank PCG and agrees bit for bit
         A = O.assemble_K(ks, d["element"], O.update_charge(d["element"], np.zeros(d["N"], np.int32),
                          O.neighbor_list(d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2]), d["metals"]),

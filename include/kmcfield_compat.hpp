@@ -1,0 +1,155 @@
+// kmcfield_compat.hpp -- drop-in definitions of the reference's extern "C" field-solve entry
+// points (src/gpu_solvers.h:36-263) on top of libkmcfield's C ABI (kmcfield.h).
+//
+// How it is used: inside the reference tree, compile ONE translation unit
+//
+//     // src/kmcfield_backend.cpp
+//     #include "kmcfield_compat.hpp"
+//
+// in place of the bodies of initialize_sparsity_K (src/iterative_solvers_gpu.cu:262-488),
+// compute_neighbor_list (src/neighbor_lists_gpu.cu:252-292), update_charge_gpu,
+// background_potential_gpu_sparse, sum_and_gather_potential (src/potential_solver_gpu.cu:66-85,
+// 846-1151) and update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70), and link
+// -lkmcfield.  src/kmc_main.cpp, Device, KMCProcess, GPUBuffers and KMC_comm stay unchanged:
+// the signatures below are the reference's own.
+//
+// This header needs the REFERENCE's headers (gpu_solvers.h -> gpu_buffers.h, KMC_comm.h, utils.h,
+// mpi.h); it is not compiled as part of this repository's library.  Error convention restored to
+// the reference's: print and exit(1) (gpuErrchk, src/utils.h:145-154).
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+
+#include "gpu_solvers.h"   // reference: GPUBuffers, KMC_comm, ELEMENT, MPI
+#include "kmcfield.h"
+
+namespace kmcf_compat {
+
+inline void check(int rc, const char *what)
+{
+    if (rc != KMCF_OK) {
+        std::fprintf(stderr, "kmcfield: %s failed (%d): %s\n", what, rc, kmcf_last_error());
+        std::exit(1);
+    }
+}
+
+// One libkmcfield communicator per MPI communicator (comm_K, comm_events ...).  The RCCL unique
+// ids are created on rank 0 and broadcast with the MPI the reference already has.
+inline kmcf_comm *comm_of(MPI_Comm mpi)
+{
+    static std::map<MPI_Comm, kmcf_comm *> table;
+    auto it = table.find(mpi);
+    if (it != table.end()) return it->second;
+    int rank = 0, size = 1, device = 0;
+    MPI_Comm_rank(mpi, &rank);
+    MPI_Comm_size(mpi, &size);
+    if (hipGetDevice(&device) != hipSuccess) { std::fprintf(stderr, "kmcfield: hipGetDevice failed\n"); std::exit(1); }
+    kmcf_comm *c = nullptr;
+    check(kmcf_comm_create(&c, device, size, rank), "kmcf_comm_create");
+    if (size > 1) {
+        char id[KMCF_UNIQUE_ID_BYTES];
+        if (rank == 0) check(kmcf_comm_unique_id(id), "kmcf_comm_unique_id");
+        MPI_Bcast(id, KMCF_UNIQUE_ID_BYTES, MPI_BYTE, 0, mpi);
+        check(kmcf_comm_connect(c, id), "kmcf_comm_connect");
+    } else {
+        check(kmcf_comm_connect(c, nullptr), "kmcf_comm_connect");
+    }
+    table[mpi] = c;
+    return c;
+}
+
+// gpubuf.K_distributed is a Distributed_matrix* in the reference; main never dereferences it
+// (it only passes gpubuf around), so the slot carries the opaque libkmcfield K state.
+inline kmcf_kstate *kstate_of(GPUBuffers &gpubuf) { return reinterpret_cast<kmcf_kstate *>(gpubuf.K_distributed); }
+
+static_assert(sizeof(ELEMENT) == sizeof(int), "ELEMENT must be a 4-byte enum (src/utils.h:37-44)");
+
+}  // namespace kmcf_compat
+
+extern "C" {
+// (plain, non-inline definitions: include this header from exactly ONE translation unit)
+
+// src/neighbor_lists_gpu.cu:252-292
+void compute_neighbor_list(MPI_Comm &event_comm, int *counts, int *displ, Device &device, GPUBuffers &gpubuf,
+                                  KMCParameters &p)
+{
+    (void)device; (void)p;
+    kmcf_comm *c = kmcf_compat::comm_of(event_comm);
+    int rank = 0;
+    MPI_Comm_rank(event_comm, &rank);
+    const int nn = 52;            // max_num_neighbors, :261
+    const double nn_dist = 3.5;   // :262
+    if (hipMalloc((void **)&gpubuf.neigh_idx, (size_t)counts[rank] * nn * sizeof(int)) != hipSuccess) std::exit(1);
+    kmcf_compat::check(kmcf_neighbor_list(c, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z, gpubuf.N_, nn_dist, nn,
+                                          counts[rank], displ[rank], gpubuf.neigh_idx), "kmcf_neighbor_list");
+}
+
+// src/iterative_solvers_gpu.cu:262-488
+void initialize_sparsity_K(GPUBuffers &gpubuf, int pbc, const double nn_dist, int num_atoms_contact,
+                                  KMC_comm &kmc_comm)
+{
+    kmcf_comm *c = kmcf_compat::comm_of(kmc_comm.comm_K);
+    double lattice[3];
+    if (hipMemcpy(lattice, gpubuf.lattice, 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) std::exit(1);
+    kmcf_kstate *k = nullptr;
+    kmcf_compat::check(kmcf_initialize_sparsity_K(c, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z, lattice, gpubuf.N_, pbc,
+                                                  nn_dist, num_atoms_contact, kmc_comm.counts_K, kmc_comm.displs_K, &k),
+                       "kmcf_initialize_sparsity_K");
+    gpubuf.K_distributed = reinterpret_cast<Distributed_matrix *>(k);
+}
+
+// src/potential_solver_gpu.cu:66-85
+void update_charge_gpu(ELEMENT *d_site_element, int *d_site_charge, int *d_neigh_idx, int N, int nn,
+                              const ELEMENT *d_metals, const int num_metals, const int *count, const int *displ,
+                              MPI_Comm &comm)
+{
+    kmcf_compat::check(kmcf_update_charge(kmcf_compat::comm_of(comm), reinterpret_cast<const int *>(d_site_element),
+                                          d_site_charge, d_neigh_idx, N, nn, reinterpret_cast<const int *>(d_metals),
+                                          num_metals, count, displ), "kmcf_update_charge");
+}
+
+// src/potential_solver_gpu.cu:846-1128 (the hipBLAS / hipSOLVER handles are unused there as well)
+void background_potential_gpu_sparse(hipblasHandle_t, hipsolverDnHandle_t, GPUBuffers &gpubuf, const int N,
+                                            const int N_left_tot, const int N_right_tot, const double Vd,
+                                            const int pbc, const double high_G, const double low_G,
+                                            const double nn_dist, const int num_metals, int kmc_step_count)
+{
+    (void)pbc; (void)nn_dist; (void)kmc_step_count;
+    kmcf_solve_stats_t st;
+    kmcf_compat::check(kmcf_background_potential_sparse(kmcf_compat::kstate_of(gpubuf),
+                                                        reinterpret_cast<const int *>(gpubuf.site_element),
+                                                        gpubuf.site_charge,
+                                                        reinterpret_cast<const int *>(gpubuf.metal_types), num_metals,
+                                                        gpubuf.site_potential_boundary, N, N_left_tot, N_right_tot, Vd,
+                                                        high_G, low_G, &st), "kmcf_background_potential_sparse");
+    // dist_conjugate_gradient.cpp:272-274
+    int rank = 0;
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    if (rank == 0)
+        std::printf("iteration K = %d, relative residual = %g\n", st.iterations + 1, st.relres);
+}
+
+// src/potential_solver_gpu.cu:1130-1151.  NB: the reference's main gathers the solution to rank 0
+// itself before this call (src/kmc_main.cpp:367-384, MPI on device pointers); libkmcfield's
+// all-gather makes that gather redundant but harmless.
+void sum_and_gather_potential(GPUBuffers &gpubuf, int num_atoms_first_layer, KMC_comm &kmc_comm)
+{
+    (void)kmc_comm;
+    kmcf_compat::check(kmcf_sum_and_gather_potential(kmcf_compat::kstate_of(gpubuf), gpubuf.site_potential_boundary,
+                                                     gpubuf.site_potential_charge, gpubuf.N_, num_atoms_first_layer),
+                       "kmcf_sum_and_gather_potential");
+}
+
+// src/heat_solver_gpu.cu:53-70
+void update_temperatureglobal_gpu(const double *site_power, double *T_bg, const int N, const double a_coeff,
+                                         const double b_coeff, const double number_steps, const double C_thermal,
+                                         const double small_step)
+{
+    kmcf_compat::check(kmcf_update_temperature_global(kmcf_compat::comm_of(MPI_COMM_WORLD), site_power, T_bg, N, a_coeff,
+                                                      b_coeff, number_steps, C_thermal, small_step),
+                       "kmcf_update_temperature_global");
+}
+
+}  // extern "C"

@@ -147,6 +147,7 @@ extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
 {
     KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_connect: null comm");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_comm_connect: host-only communicator");
+    if (c->group) return KMCF_OK;   // loopback groups are connected at creation
     // KMCF_FORCE_COMM=1 (test aid): a 1-rank group also creates its RCCL communicators and runs
     // every collective of the multi-rank code path (all-reduce of the dots, gathers)
     const bool force = getenv("KMCF_FORCE_COMM") != nullptr;
@@ -175,6 +176,12 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
 {
     if (!c) return KMCF_OK;
     if (c->device < 0) { delete c; return KMCF_OK; }
+    if (c->group) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->group->mu); last = (--c->group->refs == 0); }
+        if (last) delete c->group;
+        c->group = nullptr;
+    }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
@@ -202,9 +209,112 @@ extern "C" int kmcf_comm_sync(kmcf_comm *c)
 
 extern "C" void *kmcf_comm_stream(kmcf_comm *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
 
+// ------------------------------------------------------------------ loopback transport (tests)
+namespace {
+
+void group_barrier(kmcf_group *g)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    const long gen = g->generation;
+    if (++g->arrived == g->nranks) {
+        g->arrived = 0;
+        ++g->generation;
+        g->cv.notify_all();
+    } else {
+        g->cv.wait(lk, [&] { return g->generation != gen; });
+    }
+}
+
+int loopback_allreduce(kmcf_comm *c, double *d_buf, int count)
+{
+    kmcf_group *g = c->group;
+    KMCF_CHECK(count <= 8, KMCF_ERR_ARG, "loopback all-reduce: count %d > 8", count);
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    g->slot[c->rank] = d_buf;
+    group_barrier(g);
+    double acc[8] = {0}, tmp[8];
+    for (int q = 0; q < g->nranks; ++q) {           // rank order, like one partial per rank in MPI_Allreduce
+        KMCF_HIP(hipMemcpy(tmp, g->slot[q], (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i) acc[i] += tmp[i];
+    }
+    group_barrier(g);                                // everyone has read every slot
+    KMCF_HIP(hipMemcpy(d_buf, acc, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+int loopback_halo(kmcf_matrix *m)
+{
+    kmcf_comm *c = m->comm;
+    kmcf_group *g = c->group;
+    KMCF_HIP(hipStreamSynchronize(c->stream));       // pack kernel done
+    KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    g->mat[c->rank] = m;
+    group_barrier(g);
+    int rc = KMCF_OK;
+    for (int k = 1; k < m->number_of_neighbours && rc == KMCF_OK; ++k) {
+        const int peer = m->neighbours[k];
+        kmcf_matrix *pm = g->mat[peer];
+        int kk = -1;
+        for (int t = 1; t < pm->number_of_neighbours; ++t)
+            if (pm->neighbours[t] == c->rank) kk = t;
+        const size_t nr = m->cols_per_neighbour[k].size();
+        if (kk < 0 || pm->rows_per_neighbour[kk].size() != nr) {
+            kmcf_set_error("loopback halo: rank %d expects %zu values from rank %d, which sends %zu (matrix not structurally symmetric?)",
+                           c->rank, nr, peer, kk < 0 ? (size_t)0 : pm->rows_per_neighbour[kk].size());
+            rc = KMCF_ERR_COMM;
+            break;
+        }
+        if (nr && hipMemcpy(m->d_p + m->n_loc + m->halo_offset[k], pm->d_send_buf + pm->send_offset[kk],
+                            nr * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+            kmcf_set_error("loopback halo: hipMemcpy failed");
+            rc = KMCF_ERR_HIP;
+        }
+    }
+    group_barrier(g);                                // peers may repack now
+    return rc;
+}
+
+int loopback_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t es)
+{
+    kmcf_group *g = c->group;
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    g->slot[c->rank] = d_buf;
+    group_barrier(g);
+    for (int q = 0; q < g->nranks; ++q) {
+        if (q == c->rank || counts[q] == 0) continue;
+        KMCF_HIP(hipMemcpy(static_cast<char *>(d_buf) + (size_t)displs[q] * es,
+                           static_cast<char *>(g->slot[q]) + (size_t)displs[q] * es, (size_t)counts[q] * es,
+                           hipMemcpyDeviceToDevice));
+    }
+    group_barrier(g);
+    return KMCF_OK;
+}
+
+}  // namespace
+
+// All P ranks of an in-process loopback group at once (out: array of nranks communicators); each is
+// then driven by its own host thread.
+extern "C" int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks)
+{
+    KMCF_CHECK(out && nranks >= 1, KMCF_ERR_ARG, "kmcf_comm_create_loopback: bad argument");
+    kmcf_group *g = new kmcf_group();
+    g->nranks = nranks;
+    g->slot.assign(nranks, nullptr);
+    g->mat.assign(nranks, nullptr);
+    g->refs = nranks;
+    for (int r = 0; r < nranks; ++r) {
+        int rc = kmcf_comm_create(&out[r], device, nranks, r);
+        if (rc != KMCF_OK) return rc;
+        out[r]->group = g;
+        out[r]->connected = true;
+    }
+    return KMCF_OK;
+}
+
 // Sum `count` doubles in place over all ranks, on the compute stream, device resident.
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 {
+    if (c->group) return c->group->nranks > 1 ? loopback_allreduce(c, d_buf, count) : KMCF_OK;
     if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
     KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
     KMCF_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum,
@@ -219,6 +329,7 @@ int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 int kmcf_comm_send_recv_halo(kmcf_matrix *m)
 {
     kmcf_comm *c = m->comm;
+    if (c->group) return c->group->nranks > 1 ? loopback_halo(m) : KMCF_OK;   // every rank takes part, neighbours or not
     if (m->number_of_neighbours <= 1) return KMCF_OK;
     KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
     ncclComm_t comm = static_cast<ncclComm_t>(c->nccl);
@@ -238,6 +349,7 @@ int kmcf_comm_send_recv_halo(kmcf_matrix *m)
 template <typename T>
 static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int *displs, ncclDataType_t dt)
 {
+    if (c->group) return c->group->nranks > 1 ? loopback_allgatherv(c, d_buf, counts, displs, sizeof(T)) : KMCF_OK;
     if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
     KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
     ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_red);

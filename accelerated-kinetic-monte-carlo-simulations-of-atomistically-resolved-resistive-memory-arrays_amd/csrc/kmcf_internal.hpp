@@ -2,9 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "kmcfield.h"
@@ -52,7 +54,24 @@ struct kmcf_scalars {
     int pad[2];
 };
 
+struct kmcf_matrix;
+
+// In-process "loopback" group: the P ranks are P host threads of ONE process sharing one GPU.
+// Transport for testing the multi-rank logic (halo maps, boundary pass, reductions) on a 1-GPU
+// box, where RCCL refuses two ranks on one device.  Host-synchronous, not a performance path.
+struct kmcf_group {
+    int nranks = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    std::vector<void *> slot;            // per-rank published pointer
+    std::vector<kmcf_matrix *> mat;      // per-rank matrix taking part in the current halo exchange
+    int refs = 0;
+};
+
 struct kmcf_comm {
+    kmcf_group *group = nullptr;        // loopback transport (nullptr: RCCL)
     int device = 0;
     int nranks = 1;
     int rank = 0;

@@ -332,11 +332,15 @@ int kmcf_spmv_plan(kmcf_matrix *m)
 
 int kmcf_halo_exchange_begin(kmcf_matrix *m)
 {
-    if (m->number_of_neighbours <= 1) return KMCF_OK;
     kmcf_comm *c = m->comm;
-    const int grid = grid_for(m->n_send, KMCF_BLOCK);
-    pack_kernel<<<grid, KMCF_BLOCK, 0, c->stream>>>(m->d_send_buf, m->d_p, m->d_send_idx, m->n_send, m->d_S, 0);
-    KMCF_HIP(hipGetLastError());
+    // in a loopback group every rank takes part in the (host-synchronous) exchange, neighbours or not
+    const bool loopback = c->group && c->group->nranks > 1;
+    if (m->number_of_neighbours <= 1 && !loopback) return KMCF_OK;
+    if (m->n_send > 0) {
+        const int grid = grid_for(m->n_send, KMCF_BLOCK);
+        pack_kernel<<<grid, KMCF_BLOCK, 0, c->stream>>>(m->d_send_buf, m->d_p, m->d_send_idx, m->n_send, m->d_S, 0);
+        KMCF_HIP(hipGetLastError());
+    }
     KMCF_HIP(hipEventRecord(c->ev_packed, c->stream));
     KMCF_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
     KMCF_TRY(kmcf_comm_send_recv_halo(m));

@@ -43,6 +43,7 @@ SIGNATURES = {
     "kmcf_comm_unique_id": (C.c_int, [_P]),
     "kmcf_comm_connect": (C.c_int, [_P, _P]),
     "kmcf_comm_destroy": (C.c_int, [_P]),
+    "kmcf_comm_create_loopback": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     "kmcf_comm_sync": (C.c_int, [_P]),
     "kmcf_comm_stream": (_P, [_P]),
     "kmcf_partition": (C.c_int, [C.c_int, C.c_int, _IP, _IP]),

@@ -36,7 +36,7 @@ class KMC_comm:
     """Partition tables of src/KMC_comm.h:225-289 (split=false: every module uses
     all ranks) plus this rank's libkmcfield communicator."""
 
-    def __init__(self, nrows_K, nrows_T, nrows_pairwise, nrows_events, rank=0, size=1, device=0):
+    def __init__(self, nrows_K, nrows_T, nrows_pairwise, nrows_events, rank=0, size=1, device=0, _handle=None):
         self.lib = _L.load()
         self.rank_K = self.rank_events = self.rank_pairwise = rank
         self.size_K = self.size_events = self.size_pairwise = size
@@ -44,9 +44,22 @@ class KMC_comm:
         self.counts_pairwise, self.displs_pairwise = self.partition(nrows_pairwise, size)
         self.counts_events, self.displs_events = self.partition(nrows_events, size)
         self.device = device
-        h = C.c_void_p()
-        _L.check(self.lib.kmcf_comm_create(C.byref(h), device, size, rank), "kmcf_comm_create")
-        self.handle = h
+        self.loopback = _handle is not None
+        if _handle is None:
+            h = C.c_void_p()
+            _L.check(self.lib.kmcf_comm_create(C.byref(h), device, size, rank), "kmcf_comm_create")
+            _handle = h
+        self.handle = _handle
+
+    @classmethod
+    def loopback_group(cls, nrows_K, nrows_T, nrows_pairwise, nrows_events, size, device=0):
+        """All `size` ranks of an in-process test group on one GPU (kmcf_comm_create_loopback); each
+        returned KMC_comm must be driven by its own host thread."""
+        lib = _L.load()
+        arr = (C.c_void_p * size)()
+        _L.check(lib.kmcf_comm_create_loopback(arr, device, size), "kmcf_comm_create_loopback")
+        return [cls(nrows_K, nrows_T, nrows_pairwise, nrows_events, rank=r, size=size, device=device,
+                    _handle=C.c_void_p(arr[r])) for r in range(size)]
 
     @staticmethod
     def partition(nrows, size):
@@ -60,7 +73,7 @@ class KMC_comm:
     def connect(self, dist=None):
         """Bootstrap RCCL: rank 0 creates the unique id, torch.distributed (any
         backend) broadcasts its 128 bytes, every rank joins.  No-op for 1 rank."""
-        if self.size_K == 1:
+        if self.size_K == 1 or self.loopback:
             _L.check(self.lib.kmcf_comm_connect(self.handle, None), "kmcf_comm_connect")
             return
         assert dist is not None and dist.is_initialized(), "multi-rank groups need torch.distributed for bootstrap"

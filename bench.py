@@ -129,6 +129,16 @@ def main():
                 "kernel": "spmv_vec_kernel (CSR SpMV + fused p.Ap)", "us_per_launch": round(spmv_us, 2),
                 "algorithmic_bytes_per_launch": int(alg_bytes)}
 
+    # HBM traffic of that kernel from rocprofv3 PMC runs (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    # corrections applied by tools/pmc_summary.py); measured offline on this workload, committed under
+    # profiles/, and only reported when it was taken on the same matrix
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("rows") == n_loc and tj.get("workload") == d["name"]:
+            roofline["traffic"] = tj["corrected_bytes_per_launch"]
+            roofline["traffic_source"] = tj.get("source", "profiles/spmv_traffic.json")
+
     # ---- CPU baseline: the oracle's OpenMP PCG (same op sequence) on the host cores ---------
     cpu = None
     if vec is not None:

@@ -55,6 +55,11 @@ int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int rank);
 int kmcf_comm_unique_id(void *h_id /* KMCF_UNIQUE_ID_BYTES */);
 int kmcf_comm_connect(kmcf_comm *c, const void *h_id /* KMCF_UNIQUE_ID_BYTES */);
 int kmcf_comm_destroy(kmcf_comm *c);
+/* Test transport: all `nranks` members of an in-process group on ONE device (out: array of nranks
+ * communicators, each to be driven by its own host thread).  Collectives are host-synchronous
+ * device copies; exists because RCCL refuses two ranks on one GPU, so that the multi-rank logic
+ * (halo maps, boundary pass, reductions) can be exercised on a 1-GPU box.  Not a performance path. */
+int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks);
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
 

@@ -1,0 +1,111 @@
+"""GPU: the multi-rank field solve (row partition, compact-halo SpMV with interior/boundary split,
+per-rank partial dots + reduction, gathers) on ONE GPU, P ranks = P host threads of this process
+joined by libkmcfield's in-process loopback transport (kmcf_comm_create_loopback).  RCCL itself
+refuses two ranks on one device; this covers everything of the N>1 path except the RCCL calls,
+which tests/test_gpu_forcecomm.py exercises on a 1-rank communicator.
+
+Checked against the oracle's P-rank emulation on the reference's 5 nm device, whose shipped site
+order (type-major) makes every rank a neighbour of almost every other one (hard part 3):
+the worst case for the halo bookkeeping."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(km, d, P, ref_charge):
+    import torch
+    S = km.solvers
+    NL = d["N_contact"]
+    n_if = d["N"] - 2 * NL
+    comms = S.KMC_comm.loopback_group(n_if, d["N"] + 1, d["N"], d["N"], size=P, device=0)
+    out = [None] * P
+    errs = []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = comms[r]
+            comm.connect()
+            buf = S.GPUBuffers(d["N"], d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"],
+                               d["k"], d["lattice"], d["metals"])
+            S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
+            S.initialize_sparsity_K(buf, d["pbc"], d["nn_dist"], NL, comm)
+            S.update_charge_gpu(buf.site_element, buf.site_charge, buf.neigh_idx, buf.N_, buf.nn_, buf.metal_types,
+                                buf.num_metal_types_, comm.counts_events, comm.displs_events, comm)
+            charge = buf.site_charge.cpu().numpy().copy()
+            mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
+            info = mat.info()
+            # distributed SpMV of a known global vector
+            S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])
+            r0, nr = int(comm.displs_K[r]), int(comm.counts_K[r])
+            xg = np.cos(np.arange(n_if) * 0.37) + 1.5
+            p = torch.as_tensor(xg[r0:r0 + nr].copy(), device="cuda")
+            Ap = torch.empty_like(p)
+            mat.spmv(p, Ap)
+            st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
+                                                   d["nn_dist"], len(d["metals"]), 0)
+            S.sum_and_gather_potential(buf, NL, comm)
+            out[r] = dict(st=st, info=info, charge=charge, Ap=Ap.cpu().numpy(), r0=r0, nr=nr,
+                          v=buf.site_potential_boundary.cpu().numpy().copy(),
+                          tot=buf.site_potential_charge.cpu().numpy().copy())
+            buf.freeGPUmemory()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out), "a rank did not finish (deadlock?)"
+    for c in comms:
+        c.close()
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
+    d = dev5
+    NL = d["N_contact"]
+    ks, A = ref5["ks"], ref5["A"]
+    out = _run_ranks(km, d, P, ref5["charge"])
+    # charges: every rank computed its rows and received the others'
+    for o in out:
+        assert np.array_equal(o["charge"], ref5["charge"])
+    # halo bookkeeping equals the oracle's lists
+    for r, o in enumerate(out):
+        want = oracle.halo_lists(ks.row_ptr, ks.col, P, r)
+        assert o["info"]["number_of_neighbours"] == len(want)
+        assert o["info"]["halo_cols"] == sum(len(w["cols"]) for w in want[1:])
+    # distributed SpMV == global SpMV
+    xg = np.cos(np.arange(ks.n) * 0.37) + 1.5
+    y = oracle.spmv(ks.row_ptr, ks.col, A["val"], xg)
+    bound = oracle.spmv(ks.row_ptr, ks.col, np.abs(A["val"]), np.abs(xg))
+    for o in out:
+        sl = slice(o["r0"], o["r0"] + o["nr"])
+        assert np.all(np.abs(o["Ap"] - y[sl]) <= 1e-13 * bound[sl] + 1e-300)
+    # the solve: same iteration count on every rank, close to the oracle's P-rank emulation
+    xo, ito, relo = oracle.pcg_jacobi(ks.row_ptr, ks.col, A["val"], A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"],
+                                      10000, P=P)
+    its = {o["st"]["iterations"] for o in out}
+    assert len(its) == 1
+    it = its.pop()
+    assert abs(it - ito) <= 0.02 * ito, (it, ito)
+    for o in out:
+        assert o["st"]["converged"] == 1 and o["st"]["relres"] <= ref5["tol"]
+        # after sum_and_gather every rank holds the full interface solution
+        v = o["v"]
+        assert np.all(v[:NL] == 0) and np.all(v[-NL:] == 0)
+        dx = np.abs(v[NL:-NL] - xo)
+        assert dx.max() <= 5e-4 and np.median(dx) <= 5e-6, (dx.max(), np.median(dx))
+        res = A["rhs"] - oracle.spmv(ks.row_ptr, ks.col, A["val"], v[NL:-NL])
+        assert np.linalg.norm(res) / np.linalg.norm(A["rhs"]) <= 2e-9
+        assert np.array_equal(o["tot"], v)            # site_potential_charge (0) += boundary
+    # all ranks hold bit-identical replicated solutions
+    for o in out[1:]:
+        assert np.array_equal(o["v"], out[0]["v"])

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc runs (one counter per run, as the MI355X guide prescribes) into a per-kernel
+table and the corrected HBM traffic of the SpMV kernel.
+
+    python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01/pmc_spmv
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reports exactly
+half of the bytes of a coalesced streaming read -> doubled.  The factor is calibrated in this very run on
+kernels with a known byte count (cg_p_kernel reads 3 vectors, cg_xr_kernel reads 5 and writes 2)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in agg.items()}
+
+
+def main():
+    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    n_rows = int(sys.argv[4]) if len(sys.argv) > 4 else 1597080
+    vec = n_rows * 8.0
+    rows = []
+    for k in sorted(fetch):
+        short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        rows.append((short, fetch[k][0], fetch[k][1], write.get(k, (0, 0.0))[1]))
+    with open(out + ".csv", "w") as f:
+        f.write("kernel,calls,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean\n")
+        for r in rows:
+            f.write("%s,%d,%.1f,%.1f\n" % r)
+    def get(name):
+        return [r for r in rows if r[0].startswith(name)]
+    p = get("cg_p_kernel")[0]
+    xr = get("cg_xr_kernel")[0]
+    cal_p = p[2] * 1024 / (3 * vec)
+    cal_xr = xr[2] * 1024 / (5 * vec)
+    cal_w = xr[3] * 1024 / (2 * vec)
+    sp = max(get("spmv_"), key=lambda r: r[1])
+    corrected = 2.0 * sp[2] * 1024 + sp[3] * 1024
+    res = dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
+               calibration=dict(cg_p_fetch_ratio=round(cal_p, 4), cg_xr_fetch_ratio=round(cal_xr, 4),
+                                cg_xr_write_ratio=round(cal_w, 4)),
+               corrected_bytes_per_launch=int(corrected), rows=n_rows)
+    json.dump(res, open(out + ".json", "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -323,20 +323,22 @@ extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double
     const size_t bytes = (size_t)n * sizeof(double);
     const int g = vec_grid(n);
     double *dis = m->d_dinv;  // workspace: 1/sqrt(diag)
+    (void)bytes;
+    KMCF_TRY(kmcf_vec_in(m, m->d_r, d_rhs));
+    KMCF_TRY(kmcf_vec_in(m, m->d_x, d_x));
     diag_inv_sqrt_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_rhs, dis, 0);       // rhs scaled in place (:740)
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_r, dis, 0);      // rhs scaled (:740)
     scale_matrix_kernel<<<g * 4, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);  // :745
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_x, dis, 1);         // start guess (:751)
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 1);      // start guess (:751)
     KMCF_HIP(hipGetLastError());
-    KMCF_HIP(hipMemcpyAsync(m->d_r, d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));
-    KMCF_HIP(hipMemcpyAsync(m->d_x, d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_TRY(kmcf_vec_out(m, d_rhs, m->d_r));                                      // the caller's rhs is scaled in place
     // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
-    // the same iterates as r = b - A y, p = r used here
+    // the same iterates as r = b - A y, p = r used here.  The unpreconditioned loop never
+    // touches d_dinv, so `dis` stays intact.
     KMCF_TRY((pcg_loop<false>(m, std::sqrt(tol * tol), max_iterations, 0, 1, stats)));
-    KMCF_HIP(hipMemcpyAsync(d_x, m->d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
-    // pcg_loop<false> reuses d_dinv? no: the unpreconditioned loop never reads it, so `dis` is intact
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, d_x, dis, 0);         // y = D^-1/2 y' (:864)
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 0);      // y = D^-1/2 y' (:864)
     KMCF_HIP(hipGetLastError());
+    KMCF_TRY(kmcf_vec_out(m, d_x, m->d_x));
     KMCF_HIP(hipStreamSynchronize(c->stream));
     return KMCF_OK;
 }
@@ -351,15 +353,54 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     kmcf_comm *c = m->comm;
     KMCF_CHECK(c->connected, KMCF_ERR_COMM, "kmcf_pcg_jacobi: communicator not connected");
     KMCF_HIP(hipSetDevice(c->device));
-    const size_t bytes = (size_t)m->n_loc * sizeof(double);
     // the caller's vectors may be unaligned slices (x is gpubuf.site_potential_boundary +
-    // N_left + disp, src/potential_solver_gpu.cu:861): work on the aligned workspace
-    KMCF_HIP(hipMemcpyAsync(m->d_r, d_r, bytes, hipMemcpyDeviceToDevice, c->stream));
-    KMCF_HIP(hipMemcpyAsync(m->d_x, d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
-    if (d_diag_inv) KMCF_HIP(hipMemcpyAsync(m->d_dinv, d_diag_inv, bytes, hipMemcpyDeviceToDevice, c->stream));
+    // N_left + disp, src/potential_solver_gpu.cu:861) and are in the caller's row order: work on
+    // the aligned, internally ordered workspace
+    KMCF_TRY(kmcf_vec_in(m, m->d_r, d_r));
+    KMCF_TRY(kmcf_vec_in(m, m->d_x, d_x));
+    if (d_diag_inv) KMCF_TRY(kmcf_vec_in(m, m->d_dinv, d_diag_inv));
     KMCF_TRY(kmcf_pcg_workspace(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats));
-    KMCF_HIP(hipMemcpyAsync(d_r, m->d_r, bytes, hipMemcpyDeviceToDevice, c->stream));
-    KMCF_HIP(hipMemcpyAsync(d_x, m->d_x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KMCF_TRY(kmcf_vec_out(m, d_r, m->d_r));
+    KMCF_TRY(kmcf_vec_out(m, d_x, m->d_x));
     KMCF_HIP(hipStreamSynchronize(c->stream));   // results visible on return (:271 hipDeviceSynchronize)
+    return KMCF_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(KMCF_BLOCK) void perm_in_kernel(int n, double *__restrict__ dst, const double *__restrict__ src,
+                                                             const int *__restrict__ perm)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+__global__ __launch_bounds__(KMCF_BLOCK) void perm_out_kernel(int n, double *__restrict__ dst, const double *__restrict__ src,
+                                                              const int *__restrict__ perm)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[perm[i]] = src[i];
+}
+}  // namespace
+
+int kmcf_vec_in(kmcf_matrix *m, double *d_internal, const double *d_user)
+{
+    const int n = m->n_loc;
+    if (n == 0) return KMCF_OK;
+    if (!m->d_perm) {
+        KMCF_HIP(hipMemcpyAsync(d_internal, d_user, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, m->comm->stream));
+    } else {
+        perm_in_kernel<<<vec_grid(n), KMCF_BLOCK, 0, m->comm->stream>>>(n, d_internal, d_user, m->d_perm);
+        KMCF_HIP(hipGetLastError());
+    }
+    return KMCF_OK;
+}
+
+int kmcf_vec_out(kmcf_matrix *m, double *d_user, const double *d_internal)
+{
+    const int n = m->n_loc;
+    if (n == 0) return KMCF_OK;
+    if (!m->d_perm) {
+        KMCF_HIP(hipMemcpyAsync(d_user, d_internal, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, m->comm->stream));
+    } else {
+        perm_out_kernel<<<vec_grid(n), KMCF_BLOCK, 0, m->comm->stream>>>(n, d_user, d_internal, m->d_perm);
+        KMCF_HIP(hipGetLastError());
+    }
     return KMCF_OK;
 }

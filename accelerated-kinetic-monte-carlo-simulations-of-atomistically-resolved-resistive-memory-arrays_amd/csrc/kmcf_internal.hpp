@@ -118,6 +118,14 @@ struct kmcf_matrix {
     double *d_send_buf = nullptr;
     int *d_halo_gid = nullptr;         // global column id of each halo slot
 
+    // Internal row order.  Rows (and own-block columns, and every workspace vector) may be stored in a
+    // locality-improving order: internal row i = caller's local row perm[i].  Empty = identity.
+    // Vectors crossing the C ABI are permuted on the way in / out (kmcf_vec_in / kmcf_vec_out); the
+    // halo protocol (send / receive lists) stays in the caller's order.
+    std::vector<int> h_perm;           // internal -> caller local row
+    std::vector<int> h_row_ptr_user;   // row_ptr in the caller's order (set/get_values)
+    int *d_perm = nullptr;
+
     // CG workspace (allocated once; the reference mallocs Ap/z in create_cg_overhead)
     double *d_p = nullptr;             // n_loc + n_halo   (Distributed_vector)
     double *d_Ap = nullptr;
@@ -174,4 +182,8 @@ int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, 
 int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs);
 // matrix.hip
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
-                      const int *h_row_ptr, const int *h_col_global, const double *h_val, kmcf_matrix **out);
+                      const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                      const int *h_perm /* internal -> caller local row, or nullptr */, kmcf_matrix **out);
+// caller-order vector -> internal order (dst internal) and back, on the compute stream
+int kmcf_vec_in(kmcf_matrix *m, double *d_internal, const double *d_user);
+int kmcf_vec_out(kmcf_matrix *m, double *d_user, const double *d_internal);

@@ -40,7 +40,8 @@ int dev_alloc(T **d, size_t n)
 }  // namespace
 
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
-                      const int *h_row_ptr, const int *h_col_global, const double *h_val, kmcf_matrix **out)
+                      const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                      const int *h_perm, kmcf_matrix **out)
 {
     KMCF_CHECK(c && counts && displs && h_row_ptr && out, KMCF_ERR_ARG, "kmcf_matrix_build: null argument");
     const int P = c->nranks, rank = c->rank;
@@ -164,22 +165,62 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         for (int s = 0; s < (int)m->cols_per_neighbour[k].size(); ++s)
             halo_gid[m->halo_offset[k] + s] = displs[m->neighbours[k]] + m->cols_per_neighbour[k][s];
 
+    // ---- optional internal row order: internal row i = caller row perm[i] -------------------
+    std::vector<int> rp(h_row_ptr, h_row_ptr + n_loc + 1);
+    m->h_row_ptr_user = rp;
+    std::vector<double> val_int;
+    if (h_val) val_int.assign(h_val, h_val + nnz);
+    if (h_perm && n_loc > 0) {
+        std::vector<int> inv((size_t)n_loc, -1);
+        for (int i = 0; i < n_loc; ++i) {
+            const int r = h_perm[i];
+            if (r < 0 || r >= n_loc || inv[r] != -1) {
+                delete m;
+                kmcf_set_error("kmcf_matrix_build: perm is not a permutation of the local rows (entry %d = %d)", i, r);
+                return KMCF_ERR_ARG;
+            }
+            inv[r] = i;
+        }
+        m->h_perm.assign(h_perm, h_perm + n_loc);
+        std::vector<int> rp_new((size_t)n_loc + 1, 0), col_new((size_t)nnz);
+        std::vector<double> val_new(h_val ? (size_t)nnz : 0);
+        std::vector<unsigned char> isb_new((size_t)n_loc, 0);
+        for (int i = 0; i < n_loc; ++i) rp_new[i + 1] = rp_new[i] + (rp[h_perm[i] + 1] - rp[h_perm[i]]);
+        for (int i = 0; i < n_loc; ++i) {
+            const int r = h_perm[i];
+            int dst = rp_new[i];
+            for (int j = rp[r]; j < rp[r + 1]; ++j, ++dst) {
+                const int cl = col_local[j];
+                col_new[dst] = cl < n_loc ? inv[cl] : cl;     // own block: internal index; halo slots unchanged
+                if (h_val) val_new[dst] = h_val[j];
+            }
+            isb_new[i] = is_boundary[r];
+        }
+        rp.swap(rp_new);
+        col_local.swap(col_new);
+        val_int.swap(val_new);
+        is_boundary.swap(isb_new);
+        boundary_rows.clear();
+        for (int i = 0; i < n_loc; ++i)
+            if (is_boundary[i]) boundary_rows.push_back(i);
+        for (int &s : send_idx) s = inv[s];                   // gather positions; packed order = protocol order
+    }
+    m->h_row_ptr = rp;
+
     if (c->device < 0) {  // host-only planning communicator: no device state
         *out = m;
         return KMCF_OK;
     }
 
     KMCF_HIP(hipSetDevice(c->device));
-    std::vector<int> rp(h_row_ptr, h_row_ptr + n_loc + 1);
-    m->h_row_ptr = rp;
     KMCF_TRY(dev_upload(&m->d_row_ptr, rp));
     KMCF_TRY(dev_upload(&m->d_col, col_local));
     if (h_val) {
-        std::vector<double> v(h_val, h_val + nnz);
-        KMCF_TRY(dev_upload(&m->d_val, v));
+        KMCF_TRY(dev_upload(&m->d_val, val_int));
     } else {
         KMCF_TRY(dev_alloc(&m->d_val, (size_t)nnz));
     }
+    if (!m->h_perm.empty()) KMCF_TRY(dev_upload(&m->d_perm, m->h_perm));
     if (m->n_halo > 0) {
         KMCF_TRY(dev_upload(&m->d_is_boundary, is_boundary));
         KMCF_TRY(dev_upload(&m->d_boundary_rows, boundary_rows));
@@ -205,7 +246,7 @@ extern "C" int kmcf_matrix_create_csr(kmcf_comm *c, int matrix_size, const int *
                                       const int *h_row_ptr, const int *h_col_global, const double *h_val,
                                       kmcf_matrix **out)
 {
-    return kmcf_matrix_build(c, matrix_size, h_counts, h_displs, h_row_ptr, h_col_global, h_val, out);
+    return kmcf_matrix_build(c, matrix_size, h_counts, h_displs, h_row_ptr, h_col_global, h_val, nullptr, out);
 }
 
 extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
@@ -217,7 +258,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         hipStreamSynchronize(m->comm->comm_stream);
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
-                        m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row};
+                        m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm};
         for (void *p : ptrs)
             if (p) hipFree(p);
     }
@@ -256,7 +297,19 @@ extern "C" int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val)
     KMCF_CHECK(m && h_val, KMCF_ERR_ARG, "kmcf_matrix_set_values: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_set_values: host-only matrix");
     KMCF_HIP(hipSetDevice(m->comm->device));
-    KMCF_HIP(hipMemcpy(m->d_val, h_val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+    KMCF_HIP(hipStreamSynchronize(m->comm->stream));
+    if (m->h_perm.empty()) {
+        KMCF_HIP(hipMemcpy(m->d_val, h_val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        // creation order -> internal order, row by row (entries keep their order inside a row)
+        std::vector<double> v((size_t)m->nnz);
+        for (int i = 0; i < m->n_loc; ++i) {
+            const int r = m->h_perm[i];
+            const int len = m->h_row_ptr_user[r + 1] - m->h_row_ptr_user[r];
+            if (len) memcpy(&v[m->h_row_ptr[i]], &h_val[m->h_row_ptr_user[r]], (size_t)len * sizeof(double));
+        }
+        KMCF_HIP(hipMemcpy(m->d_val, v.data(), (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
     return KMCF_OK;
 }
 
@@ -266,6 +319,16 @@ extern "C" int kmcf_matrix_get_values(const kmcf_matrix *m, double *h_val)
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_get_values: host-only matrix");
     KMCF_HIP(hipSetDevice(m->comm->device));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
-    KMCF_HIP(hipMemcpy(h_val, m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (m->h_perm.empty()) {
+        KMCF_HIP(hipMemcpy(h_val, m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<double> v((size_t)m->nnz);
+        KMCF_HIP(hipMemcpy(v.data(), m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < m->n_loc; ++i) {
+            const int r = m->h_perm[i];
+            const int len = m->h_row_ptr_user[r + 1] - m->h_row_ptr_user[r];
+            if (len) memcpy(&h_val[m->h_row_ptr_user[r]], &v[m->h_row_ptr[i]], (size_t)len * sizeof(double));
+        }
+    }
     return KMCF_OK;
 }

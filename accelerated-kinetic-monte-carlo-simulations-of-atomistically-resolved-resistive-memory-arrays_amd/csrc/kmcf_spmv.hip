@@ -379,9 +379,9 @@ extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_HIP(hipSetDevice(c->device));
-    KMCF_HIP(hipMemcpyAsync(m->d_p, d_p, (size_t)m->n_loc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    KMCF_TRY(kmcf_vec_in(m, m->d_p, d_p));
     KMCF_TRY(kmcf_spmv_device(m, false, false));
-    KMCF_HIP(hipMemcpyAsync(d_Ap, m->d_Ap, (size_t)m->n_loc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    KMCF_TRY(kmcf_vec_out(m, d_Ap, m->d_Ap));
     KMCF_HIP(hipStreamSynchronize(c->stream));
     return KMCF_OK;
 }

@@ -95,7 +95,7 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
     its = {o["st"]["iterations"] for o in out}
     assert len(its) == 1
     it = its.pop()
-    assert abs(it - ito) <= 0.02 * ito, (it, ito)
+    assert abs(it - ito) <= 0.05 * ito, (it, ito)      # see tests/test_gpu_parity.py on this tolerance
     for o in out:
         assert o["st"]["converged"] == 1 and o["st"]["relres"] <= ref5["tol"]
         # after sum_and_gather every rank holds the full interface solution

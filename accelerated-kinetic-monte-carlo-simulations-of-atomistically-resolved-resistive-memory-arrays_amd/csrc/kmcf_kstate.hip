@@ -687,12 +687,16 @@ extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_sit
 }
 
 extern "C" int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_potential_boundary,
-                                             double *d_site_potential_charge, int N, int num_atoms_first_layer)
+                                             double *d_site_potential_charge, int N, int num_atoms_first_layer,
+                                             const int *h_counts_pairwise, const int *h_displs_pairwise)
 {
     KMCF_CHECK(k && d_site_potential_boundary && d_site_potential_charge, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: null argument");
     KMCF_CHECK(N == k->N && num_atoms_first_layer == k->N_left, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: size mismatch");
     kmcf_comm *c = k->comm;
     KMCF_HIP(hipSetDevice(c->device));
+    // pairwise term: every rank computed its rows (src/kmc_main.cpp:405-425, potential_solver_gpu.cu:1139-1142)
+    if (h_counts_pairwise && h_displs_pairwise)
+        KMCF_TRY(kmcf_comm_allgatherv_double(c, d_site_potential_charge, h_counts_pairwise, h_displs_pairwise));
     // MPI_Gatherv to rank 0 (src/kmc_main.cpp:367-384) + MPI_Bcast (potential_solver_gpu.cu:1133-1136)
     KMCF_TRY(kmcf_comm_allgatherv_double(c, d_site_potential_boundary + num_atoms_first_layer,
                                          k->K->counts.data(), k->K->displs.data()));

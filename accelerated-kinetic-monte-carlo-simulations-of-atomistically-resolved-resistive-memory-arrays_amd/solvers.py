@@ -123,12 +123,16 @@ class GPUBuffers:
         self.lattice_host = np.asarray(lattice, np.float64)
         self.sigma, self.k = float(sigma), float(k)
         self.neigh_idx = None
+        self.cutoff_idx = None         # kmcf_pairwise* (replaces cutoff_idx / cutoff_window)
         self.K_distributed = None      # kmcf_kstate* (K_distributed + K_p_distributed + contact patterns)
 
     def freeGPUmemory(self):
         if self.K_distributed is not None:
             _L.load().kmcf_kstate_destroy(self.K_distributed)
             self.K_distributed = None
+        if self.cutoff_idx is not None:
+            _L.load().kmcf_pairwise_destroy(self.cutoff_idx)
+            self.cutoff_idx = None
 
 
 # --------------------------------------------------------------------------
@@ -188,9 +192,35 @@ def sum_and_gather_potential(gpubuf, num_atoms_first_layer, kmc_comm):
     """sum_and_gather_potential (gpu_solvers.h:181; src/potential_solver_gpu.cu:1130-1151) including the
     MPI_Gatherv of the solution done by the caller in the reference (src/kmc_main.cpp:367-384)."""
     lib = _L.load()
+    cp = dp = None
+    if getattr(gpubuf, "cutoff_idx", None) is not None:     # the pairwise term is in use: gather its rows too
+        c_, cp = _ia(kmc_comm.counts_pairwise)
+        d_, dp = _ia(kmc_comm.displs_pairwise)
     _L.check(lib.kmcf_sum_and_gather_potential(gpubuf.K_distributed, _ptr(gpubuf.site_potential_boundary),
                                                _ptr(gpubuf.site_potential_charge), gpubuf.N_,
-                                               int(num_atoms_first_layer)), "kmcf_sum_and_gather_potential")
+                                               int(num_atoms_first_layer), cp, dp), "kmcf_sum_and_gather_potential")
+
+
+def compute_cutoff_list(kmc_comm, gpubuf, cutoff_radius=20.0):
+    """compute_cutoff_list (gpu_solvers.h:46; src/neighbor_lists_gpu.cu:293-372).  gpubuf.cutoff_idx becomes
+    the opaque spatial index that replaces the reference's N x N_cutoff index list."""
+    lib = _L.load()
+    h = C.c_void_p()
+    _L.check(lib.kmcf_compute_cutoff_list(kmc_comm.handle, _ptr(gpubuf.site_x), _ptr(gpubuf.site_y),
+                                          _ptr(gpubuf.site_z), gpubuf.N_, float(cutoff_radius), C.byref(h)),
+             "kmcf_compute_cutoff_list")
+    gpubuf.cutoff_idx = h
+
+
+def poisson_gridless_gpu(gpubuf, kmc_comm):
+    """poisson_gridless_gpu (gpu_solvers.h:173; src/potential_solver_gpu.cu:1620-1655): the rows of this
+    rank of site_potential_charge."""
+    lib = _L.load()
+    r = kmc_comm.rank_pairwise
+    _L.check(lib.kmcf_poisson_gridless(gpubuf.cutoff_idx, _ptr(gpubuf.site_x), _ptr(gpubuf.site_y), _ptr(gpubuf.site_z),
+                                       _ptr(gpubuf.site_charge), gpubuf.sigma, gpubuf.k,
+                                       int(kmc_comm.counts_pairwise[r]), int(kmc_comm.displs_pairwise[r]),
+                                       _ptr(gpubuf.site_potential_charge)), "kmcf_poisson_gridless")
 
 
 def update_temperatureglobal_gpu(site_power, T_bg, N, a_coeff, b_coeff, number_steps, C_thermal, small_step,

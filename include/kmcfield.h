@@ -192,9 +192,32 @@ int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_site_element, 
 /* The MPI_Gatherv of the solution (src/kmc_main.cpp:367-384) + the two
  * MPI_Bcast + sum_AB_into_A of sum_and_gather_potential
  * (src/potential_solver_gpu.cu:1130-1151): replicates the interface solution
- * on every rank and does site_potential_charge += site_potential_boundary. */
+ * on every rank and does site_potential_charge += site_potential_boundary.
+ * h_counts_pairwise / h_displs_pairwise (kmc_comm.counts_pairwise, displs_pairwise;
+ * may be NULL): the rows of site_potential_charge each rank computed with
+ * kmcf_poisson_gridless, all-gathered first (the MPI_Gatherv of src/kmc_main.cpp:
+ * 405-425 + the MPI_Bcast of potential_solver_gpu.cu:1139-1142). */
 int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_potential_boundary,
-                                  double *d_site_potential_charge, int N, int num_atoms_first_layer);
+                                  double *d_site_potential_charge, int N, int num_atoms_first_layer,
+                                  const int *h_counts_pairwise, const int *h_displs_pairwise);
+
+/* ---------------------------------------------------------------------- */
+/* Short-range pairwise Poisson term                           */
+/* ---------------------------------------------------------------------- */
+typedef struct kmcf_pairwise kmcf_pairwise;
+
+/* compute_cutoff_list (src/neighbor_lists_gpu.cu:293-372; cutoff 20 A there): one-off
+ * spatial index of the sites; replaces the N x N_cutoff index list (gpubuf.cutoff_idx). */
+int kmcf_compute_cutoff_list(kmcf_comm *c, const double *d_x, const double *d_y, const double *d_z, int N,
+                             double cutoff_radius, kmcf_pairwise **out);
+int kmcf_pairwise_destroy(kmcf_pairwise *p);
+
+/* poisson_gridless_gpu (src/potential_solver_gpu.cu:1620-1655): for the sites
+ * [displ, displ+count): site_potential_charge[i] = sum over charged sites j != i within
+ * the cutoff of q_j erfc(r/(sigma sqrt 2)) k q / r  (v_solve_gpu, src/gpu_solvers.h:321-329). */
+int kmcf_poisson_gridless(kmcf_pairwise *p, const double *d_x, const double *d_y, const double *d_z,
+                          const int *d_site_charge, double sigma, double k, int count, int displ,
+                          double *d_site_potential_charge);
 
 /* update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70). */
 int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,

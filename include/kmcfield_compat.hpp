@@ -136,10 +136,38 @@ void background_potential_gpu_sparse(hipblasHandle_t, hipsolverDnHandle_t, GPUBu
 // all-gather makes that gather redundant but harmless.
 void sum_and_gather_potential(GPUBuffers &gpubuf, int num_atoms_first_layer, KMC_comm &kmc_comm)
 {
-    (void)kmc_comm;
     kmcf_compat::check(kmcf_sum_and_gather_potential(kmcf_compat::kstate_of(gpubuf), gpubuf.site_potential_boundary,
-                                                     gpubuf.site_potential_charge, gpubuf.N_, num_atoms_first_layer),
+                                                     gpubuf.site_potential_charge, gpubuf.N_, num_atoms_first_layer,
+                                                     kmc_comm.counts_pairwise, kmc_comm.displs_pairwise),
                        "kmcf_sum_and_gather_potential");
+}
+
+// src/neighbor_lists_gpu.cu:293-372: gpubuf.cutoff_idx (int*) carries the opaque spatial index
+void compute_cutoff_list(MPI_Comm &pairwise_comm, int *counts, int *displ, Device &device, GPUBuffers &gpubuf,
+                         KMCParameters &p)
+{
+    (void)counts; (void)displ; (void)device; (void)p;
+    kmcf_pairwise *pw = nullptr;
+    kmcf_compat::check(kmcf_compute_cutoff_list(kmcf_compat::comm_of(pairwise_comm), gpubuf.site_x, gpubuf.site_y,
+                                                gpubuf.site_z, gpubuf.N_, 20.0 /* :298 */, &pw), "kmcf_compute_cutoff_list");
+    gpubuf.cutoff_idx = reinterpret_cast<int *>(pw);
+    gpubuf.N_cutoff_ = 0;
+}
+
+// src/potential_solver_gpu.cu:1620-1655 (sigma and k are device scalars in the reference)
+void poisson_gridless_gpu(const int num_atoms_contact, const int pbc, const int N, const double *lattice,
+                          const double *sigma, const double *k, const double *posx, const double *posy,
+                          const double *posz, const int *site_charge, double *site_potential_charge, const int rank,
+                          const int size, const int *count, const int *displ, const int *cutoff_window,
+                          const int *cutoff_idx, const int N_cutoff)
+{
+    (void)num_atoms_contact; (void)pbc; (void)N; (void)lattice; (void)size; (void)cutoff_window; (void)N_cutoff;
+    double hs = 0, hk = 0;
+    if (hipMemcpy(&hs, sigma, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&hk, k, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) std::exit(1);
+    kmcf_pairwise *pw = reinterpret_cast<kmcf_pairwise *>(const_cast<int *>(cutoff_idx));
+    kmcf_compat::check(kmcf_poisson_gridless(pw, posx, posy, posz, site_charge, hs, hk, count[rank], displ[rank],
+                                             site_potential_charge), "kmcf_poisson_gridless");
 }
 
 // src/heat_solver_gpu.cu:53-70

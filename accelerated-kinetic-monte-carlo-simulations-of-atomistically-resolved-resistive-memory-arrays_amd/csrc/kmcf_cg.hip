@@ -311,6 +311,30 @@ __global__ __launch_bounds__(KMCF_BLOCK) void scale_vector_kernel(int n, double 
 
 }  // namespace
 
+// solve_sparse_CG_Jacobi on the workspace: m->d_r = rhs, m->d_x = start guess (internal order).
+// Scales A (in place), rhs and the guess, solves, un-scales the solution into m->d_x.  If d_rhs_user is
+// given, the scaled rhs is written back to it (the reference scales the caller's rhs in place, :740).
+int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, double *d_rhs_user, kmcf_solve_stats_t *stats)
+{
+    kmcf_comm *c = m->comm;
+    const int n = m->n_loc;
+    const int g = vec_grid(n);
+    double *dis = m->d_dinv;  // workspace: 1/sqrt(diag)
+    diag_inv_sqrt_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_r, dis, 0);      // rhs scaled (:740)
+    scale_matrix_kernel<<<g * 4, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);  // :745
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 1);      // start guess (:751)
+    KMCF_HIP(hipGetLastError());
+    if (d_rhs_user) KMCF_TRY(kmcf_vec_out(m, d_rhs_user, m->d_r));
+    // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
+    // the same iterates as r = b - A y, p = r used here.  The unpreconditioned loop never
+    // touches d_dinv, so `dis` stays intact.
+    KMCF_TRY((pcg_loop<false>(m, std::sqrt(tol * tol), max_iterations, 0, 1, stats)));
+    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 0);      // y = D^-1/2 y' (:864)
+    KMCF_HIP(hipGetLastError());
+    return KMCF_OK;
+}
+
 extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double *d_x, double tol, int max_iterations,
                                            kmcf_solve_stats_t *stats)
 {
@@ -319,25 +343,9 @@ extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double
     KMCF_CHECK(m->comm->nranks == 1, KMCF_ERR_ARG, "kmcf_solve_sparse_CG_Jacobi: single-rank solver (reference: one GPU)");
     kmcf_comm *c = m->comm;
     KMCF_HIP(hipSetDevice(c->device));
-    const int n = m->n_loc;
-    const size_t bytes = (size_t)n * sizeof(double);
-    const int g = vec_grid(n);
-    double *dis = m->d_dinv;  // workspace: 1/sqrt(diag)
-    (void)bytes;
     KMCF_TRY(kmcf_vec_in(m, m->d_r, d_rhs));
     KMCF_TRY(kmcf_vec_in(m, m->d_x, d_x));
-    diag_inv_sqrt_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_r, dis, 0);      // rhs scaled (:740)
-    scale_matrix_kernel<<<g * 4, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);  // :745
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 1);      // start guess (:751)
-    KMCF_HIP(hipGetLastError());
-    KMCF_TRY(kmcf_vec_out(m, d_rhs, m->d_r));                                      // the caller's rhs is scaled in place
-    // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
-    // the same iterates as r = b - A y, p = r used here.  The unpreconditioned loop never
-    // touches d_dinv, so `dis` stays intact.
-    KMCF_TRY((pcg_loop<false>(m, std::sqrt(tol * tol), max_iterations, 0, 1, stats)));
-    scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 0);      // y = D^-1/2 y' (:864)
-    KMCF_HIP(hipGetLastError());
+    KMCF_TRY(kmcf_scaled_cg_workspace(m, tol, max_iterations, d_rhs, stats));
     KMCF_TRY(kmcf_vec_out(m, d_x, m->d_x));
     KMCF_HIP(hipStreamSynchronize(c->stream));
     return KMCF_OK;

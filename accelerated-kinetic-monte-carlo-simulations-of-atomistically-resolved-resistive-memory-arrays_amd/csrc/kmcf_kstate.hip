@@ -231,7 +231,15 @@ __global__ __launch_bounds__(KMCF_BLOCK) void site_class_kernel(const int *__res
 // Row sums are formed from integer counts (n_high*high_G + n_low*low_G): independent of
 // lane order and of the rank count (the reference adds the values block by block in
 // column order, src/potential_solver_gpu.cu:774-794 -- equal up to a few ulp).
-template <int LPR>
+// CB = true: conduction-band-edge Laplace system, G = high_G iff EITHER site is a metal
+// (calc_off_diagonal_A_CB_gpu, src/potential_solver_gpu.cu:289-319).
+template <bool CB>
+__device__ __forceinline__ bool high_rule(unsigned char ci, unsigned char cj)
+{
+    return CB ? (((ci | cj) & 1) != 0) : ((ci & cj) != 0);
+}
+
+template <int LPR, bool CB>
 __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
     int n_loc, int row_site0 /* N_left + displ */, int n_left, int n_interface,
     const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ val,
@@ -259,16 +267,16 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
                 if (j == dpos) continue;
                 const int c = col[j];
                 const int site = (c < n_loc) ? (row_site0 + (perm ? perm[c] : c)) : (n_left + halo_gid[c - n_loc]);
-                const bool high = (ci & cls[site]) != 0;
+                const bool high = high_rule<CB>(ci, cls[site]);
                 val[j] = high ? -high_G : -low_G;
                 nh += high; nl += !high;
             }
             for (int j = left_row_ptr[ru] + lane; j < left_row_ptr[ru + 1]; j += LPR) {
-                const bool high = (ci & cls[left_col[j]]) != 0;
+                const bool high = high_rule<CB>(ci, cls[left_col[j]]);
                 lh += high; ll += !high;
             }
             for (int j = right_row_ptr[ru] + lane; j < right_row_ptr[ru + 1]; j += LPR) {
-                const bool high = (ci & cls[n_left + n_interface + right_col[j]]) != 0;
+                const bool high = high_rule<CB>(ci, cls[n_left + n_interface + right_col[j]]);
                 rh += high; rl += !high;
             }
         }
@@ -591,8 +599,14 @@ extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *
     return KMCF_OK;
 }
 
+#define KMCF_ASM_ARGS(VL, VR)                                                                                          \
+    m->n_loc, k->N_left + m->row0, k->N_left, k->N_interface, m->d_row_ptr, m->d_col, m->d_val, k->d_diag_pos,          \
+        m->d_halo_gid, m->d_perm, k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls,      \
+        high_G, low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs
+
 static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
-                            const int *d_metals, int num_metals, double Vd, double high_G, double low_G)
+                            const int *d_metals, int num_metals, double Vd, double high_G, double low_G,
+                            bool cb_rule = false)
 {
     kmcf_comm *c = k->comm;
     kmcf_matrix *m = k->K;
@@ -600,14 +614,57 @@ static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int
     KMCF_HIP(hipGetLastError());
     if (m->n_loc > 0) {
         constexpr int LPR = 16;
-        k_assemble_kernel<LPR><<<grid1d((int64_t)m->n_loc * LPR), KMCF_BLOCK, 0, c->stream>>>(
-            m->n_loc, k->N_left + m->row0, k->N_left, k->N_interface, m->d_row_ptr, m->d_col, m->d_val, k->d_diag_pos,
-            m->d_halo_gid, m->d_perm, k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls, high_G, low_G,
-            -Vd / 2, Vd / 2,                                                     // :866-867
-            k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs);
+        const int grid = grid1d((int64_t)m->n_loc * LPR);
+        if (!cb_rule)
+            k_assemble_kernel<LPR, false><<<grid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASM_ARGS(-Vd / 2, Vd / 2));   // :866-867
+        else
+            k_assemble_kernel<LPR, true><<<grid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASM_ARGS(Vd / 2, -Vd / 2));    // :697-698
         KMCF_HIP(hipGetLastError());
     }
     k->assembled = true;
+    return KMCF_OK;
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void cb_finish_kernel(double *__restrict__ cb, int N, int n_left, int n_interface,
+                                                               double Vd, double eV_to_J)
+{
+    // boundary fill (src/potential_solver_gpu.cu:746-749) + hipblasDscal by eV_to_J (:752)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        double v = cb[i];
+        if (i < n_left) v = Vd / 2;
+        else if (i >= n_left + n_interface) v = -Vd / 2;
+        cb[i] = v * eV_to_J;
+    }
+}
+
+int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, double *d_rhs_user, kmcf_solve_stats_t *stats);
+
+// update_CB_edge_gpu_sparse (src/potential_solver_gpu.cu:673-772): Laplace solve for the conduction-band
+// edge on the K pattern (the reference rebuilds an identical single-GPU pattern, initialize_sparsity_CB),
+// "either site metal" conductances, contacts at +Vd/2 / -Vd/2, solve_sparse_CG_Jacobi (tol 1e-14),
+// result x eV_to_J.  Start guess = current content of site_CB_edge (:732).  Single rank, like the reference.
+extern "C" int kmcf_update_CB_edge_sparse(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                                          const int *d_metals, int num_metals, double *d_site_CB_edge, int N,
+                                          int N_left_tot, int N_right_tot, double Vd, double high_G, double low_G,
+                                          kmcf_solve_stats_t *stats)
+{
+    KMCF_CHECK(k && d_site_element && d_site_charge && d_metals && d_site_CB_edge, KMCF_ERR_ARG, "kmcf_update_CB_edge_sparse: null argument");
+    KMCF_CHECK(N == k->N && N_left_tot == k->N_left && N_right_tot == k->N_right, KMCF_ERR_ARG,
+               "kmcf_update_CB_edge_sparse: N/N_left/N_right differ from the pattern's");
+    kmcf_comm *c = k->comm;
+    kmcf_matrix *m = k->K;
+    KMCF_CHECK(c->nranks == 1, KMCF_ERR_ARG, "kmcf_update_CB_edge_sparse: single-rank solve (the reference runs it on one GPU)");
+    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G, true));
+    // (the matrix now holds the CB system: values, diag, rhs; the next kmcf_k_assemble refills K)
+    KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, (size_t)m->n_loc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double *v_soln = d_site_CB_edge + N_left_tot;
+    KMCF_TRY(kmcf_vec_in(m, m->d_x, v_soln));
+    KMCF_TRY(kmcf_scaled_cg_workspace(m, 1e-14 /* :719 */, 50000 /* warning threshold :860 */, nullptr, stats));
+    KMCF_TRY(kmcf_vec_out(m, v_soln, m->d_x));
+    cb_finish_kernel<<<grid1d(N), KMCF_BLOCK, 0, c->stream>>>(d_site_CB_edge, N, N_left_tot, k->N_interface, Vd, 1.60217663e-19);
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipStreamSynchronize(c->stream));
     return KMCF_OK;
 }
 

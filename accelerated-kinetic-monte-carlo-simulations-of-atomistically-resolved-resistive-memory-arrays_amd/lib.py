@@ -72,6 +72,8 @@ SIGNATURES = {
     "kmcf_background_potential_sparse": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                                    C.c_double, C.c_double, C.c_double, C.POINTER(SolveStats)]),
     "kmcf_sum_and_gather_potential": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _IP, _IP]),
+    "kmcf_update_CB_edge_sparse": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                             C.c_double, C.c_double, C.c_double, C.POINTER(SolveStats)]),
     "kmcf_compute_cutoff_list": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.POINTER(_P)]),
     "kmcf_pairwise_destroy": (C.c_int, [_P]),
     "kmcf_poisson_gridless": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_int, C.c_int, _P]),

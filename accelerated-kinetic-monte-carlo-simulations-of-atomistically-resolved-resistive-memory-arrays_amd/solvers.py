@@ -188,6 +188,20 @@ def background_potential_gpu_sparse(gpubuf, N, N_left_tot, N_right_tot, Vd, pbc,
     return st.as_dict()
 
 
+def update_CB_edge_gpu_sparse(gpubuf, N, N_left_tot, N_right_tot, Vd, pbc, high_G, low_G, nn_dist, num_metals):
+    """update_CB_edge_gpu_sparse (gpu_solvers.h:143; src/potential_solver_gpu.cu:673-772): writes
+    gpubuf.site_CB_edge [J]."""
+    lib = _L.load()
+    if getattr(gpubuf, "site_CB_edge", None) is None:
+        gpubuf.site_CB_edge = torch.zeros(gpubuf.N_, dtype=torch.float64, device=gpubuf.device)
+    st = _L.SolveStats()
+    _L.check(lib.kmcf_update_CB_edge_sparse(gpubuf.K_distributed, _ptr(gpubuf.site_element), _ptr(gpubuf.site_charge),
+                                            _ptr(gpubuf.metal_types), int(num_metals), _ptr(gpubuf.site_CB_edge),
+                                            int(N), int(N_left_tot), int(N_right_tot), float(Vd), float(high_G),
+                                            float(low_G), C.byref(st)), "kmcf_update_CB_edge_sparse")
+    return st.as_dict()
+
+
 def sum_and_gather_potential(gpubuf, num_atoms_first_layer, kmc_comm):
     """sum_and_gather_potential (gpu_solvers.h:181; src/potential_solver_gpu.cu:1130-1151) including the
     MPI_Gatherv of the solution done by the caller in the reference (src/kmc_main.cpp:367-384)."""

@@ -189,6 +189,17 @@ int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_site_element, 
                                      int N, int N_left_tot, int N_right_tot, double Vd,
                                      double high_G, double low_G, kmcf_solve_stats_t *stats);
 
+/* update_CB_edge_gpu_sparse (src/potential_solver_gpu.cu:575-772): Laplace solve for the
+ * conduction-band edge on the K pattern: G = high_G if EITHER site is a metal (:289-319),
+ * contacts at +Vd/2 (left) / -Vd/2 (right), solve_sparse_CG_Jacobi (tol 1e-14), boundary
+ * fill and scaling by eV_to_J = 1.60217663e-19.  d_site_CB_edge: N doubles, in/out (its
+ * interface slice is the start guess, :732).  Single-rank, like the reference.  Overwrites
+ * the K values of the state (the next kmcf_k_assemble refills them). */
+int kmcf_update_CB_edge_sparse(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
+                               const int *d_metals, int num_metals, double *d_site_CB_edge, int N,
+                               int N_left_tot, int N_right_tot, double Vd, double high_G, double low_G,
+                               kmcf_solve_stats_t *stats);
+
 /* The MPI_Gatherv of the solution (src/kmc_main.cpp:367-384) + the two
  * MPI_Bcast + sum_AB_into_A of sum_and_gather_potential
  * (src/potential_solver_gpu.cu:1130-1151): replicates the interface solution

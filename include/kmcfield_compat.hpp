@@ -131,6 +131,21 @@ void background_potential_gpu_sparse(hipblasHandle_t, hipsolverDnHandle_t, GPUBu
         std::printf("iteration K = %d, relative residual = %g\n", st.iterations + 1, st.relres);
 }
 
+// src/potential_solver_gpu.cu:673-772 (single GPU; needs initialize_sparsity_K to have run)
+void update_CB_edge_gpu_sparse(hipblasHandle_t, hipsolverDnHandle_t, GPUBuffers &gpubuf, const int N,
+                               const int N_left_tot, const int N_right_tot, const double d_Vd, const int pbc,
+                               const double d_high_G, const double d_low_G, const double nn_dist, const int num_metals)
+{
+    (void)pbc; (void)nn_dist;
+    kmcf_solve_stats_t st;
+    kmcf_compat::check(kmcf_update_CB_edge_sparse(kmcf_compat::kstate_of(gpubuf),
+                                                  reinterpret_cast<const int *>(gpubuf.site_element), gpubuf.site_charge,
+                                                  reinterpret_cast<const int *>(gpubuf.metal_types), num_metals,
+                                                  gpubuf.site_CB_edge, N, N_left_tot, N_right_tot, d_Vd, d_high_G, d_low_G,
+                                                  &st), "kmcf_update_CB_edge_sparse");
+    std::printf("# CG steps: %d\n", st.iterations);   // src/iterative_solvers_gpu.cu:862
+}
+
 // src/potential_solver_gpu.cu:1130-1151.  NB: the reference's main gathers the solution to rank 0
 // itself before this call (src/kmc_main.cpp:367-384, MPI on device pointers); libkmcfield's
 // all-gather makes that gather redundant but harmless.

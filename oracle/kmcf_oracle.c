@@ -370,6 +370,92 @@ void orc_assemble_K(const int *element, const int *charge, const int *metals, in
     }
 }
 
+void orc_spmv(int n, const int *row_ptr, const int *col, const double *val, const double *x, double *y);
+static double dot_pairwise(const double *a, const double *b, int n);
+
+/*
+ * Conduction-band-edge Laplace system, Assemble_A_CB + update_CB_edge_gpu_sparse,
+ * src/potential_solver_gpu.cu:575-772 (single GPU in the reference):
+ *   - off-diagonals -G with G = high_G if EITHER site is a metal (calc_off_diagonal_A_CB_gpu, :289-319)
+ *   - diagonal = sum of G over interface neighbours (reduce_rows_into_diag, 4-argument form)
+ *                + left + right contact sums, same "either metal" rule
+ *                (row_reduce_K_CB_off_diagonal_block_with_precomputing :371-419, add_vector_to_diagonal)
+ *   - rhs = left * (+Vd/2) + right * (-Vd/2)     (:697-698: the sign is opposite to the K system)
+ */
+void orc_assemble_CB(const int *element, const int *metals, int num_metals,
+                     double high_G, double low_G, double Vd, int N_left, int N_interface,
+                     const int *row_ptr, const int *col, double *val,
+                     const int *left_row_ptr, const int *left_col,
+                     const int *right_row_ptr, const int *right_col, double *rhs)
+{
+    double VL = Vd / 2, VR = -Vd / 2;
+    for (int r = 0; r < N_interface; ++r) {
+        int i = N_left + r;
+        int m1 = is_in_array(metals, element[i], num_metals);
+        double diag = 0.0;
+        for (int jd = row_ptr[r]; jd < row_ptr[r + 1]; ++jd) {
+            if (col[jd] == r) { val[jd] = 0.0; continue; }
+            int m2 = is_in_array(metals, element[N_left + col[jd]], num_metals);
+            val[jd] = -((m1 || m2) ? high_G : low_G);
+            diag -= val[jd];
+        }
+        double l = 0.0, rr = 0.0;
+        for (int c = left_row_ptr[r]; c < left_row_ptr[r + 1]; ++c)
+            l += (m1 || is_in_array(metals, element[left_col[c]], num_metals)) ? high_G : low_G;
+        for (int c = right_row_ptr[r]; c < right_row_ptr[r + 1]; ++c)
+            rr += (m1 || is_in_array(metals, element[N_left + N_interface + right_col[c]], num_metals)) ? high_G : low_G;
+        for (int jd = row_ptr[r]; jd < row_ptr[r + 1]; ++jd)
+            if (col[jd] == r) val[jd] = diag + l + rr;
+        rhs[r] = l * VL + rr * VR;
+    }
+}
+
+/*
+ * solve_sparse_CG_Jacobi, src/iterative_solvers_gpu.cu:716-887: CG on the symmetrically scaled
+ * system D^-1/2 A D^-1/2 with the reference's sign convention (r = A y - b, p = -r) and its stopping
+ * test: first on ||r|| (hipblasDnrm2, :838), afterwards on ||r||^2 (hipblasDdot, :858), both against
+ * tol^2.  A values and b are scaled IN PLACE; y: start guess in, solution out.  max_it bounds the
+ * loop (the reference's loop is unbounded).  Returns the iteration count.
+ */
+int orc_solve_sparse_CG_Jacobi(int n, const int *row_ptr, const int *col, double *val,
+                               double *b, double *y, double tol, int max_it)
+{
+    double *dis = (double *)malloc((size_t)n * sizeof(double));
+    double *r = (double *)malloc((size_t)n * sizeof(double));
+    double *p = (double *)malloc((size_t)n * sizeof(double));
+    double *tmp = (double *)malloc((size_t)n * sizeof(double));
+    for (int i = 0; i < n; ++i) {                                        /* computeDiagonalInvSqrt :630-652 */
+        double d = 0.0;
+        for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j) if (col[j] == i) { d = val[j]; break; }
+        dis[i] = 1.0 / sqrt(d);
+    }
+    for (int i = 0; i < n; ++i) b[i] = b[i] * dis[i];                    /* :740 */
+    for (int i = 0; i < n; ++i)                                          /* :745 */
+        for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j) val[j] = val[j] * dis[i] * dis[col[j]];
+    for (int i = 0; i < n; ++i) y[i] = y[i] * 1 / dis[i];                /* :751 */
+    orc_spmv(n, row_ptr, col, val, y, r);                                /* r = A y */
+    for (int i = 0; i < n; ++i) r[i] += -1.0 * b[i];                     /* r = -b + r */
+    for (int i = 0; i < n; ++i) p[i] = -r[i];
+    double h_norm = sqrt(dot_pairwise(r, r, n));                         /* Dnrm2 */
+    int counter = 0;
+    while (h_norm > tol * tol && counter < max_it) {
+        double t = dot_pairwise(r, r, n);
+        orc_spmv(n, row_ptr, col, val, p, tmp);
+        double alpha = t / dot_pairwise(p, tmp, n);
+        for (int i = 0; i < n; ++i) y[i] += alpha * p[i];
+        for (int i = 0; i < n; ++i) r[i] += alpha * tmp[i];
+        double tnew = dot_pairwise(r, r, n);
+        double beta = tnew / t;
+        for (int i = 0; i < n; ++i) p[i] = p[i] * beta;
+        for (int i = 0; i < n; ++i) p[i] += -1.0 * r[i];
+        h_norm = dot_pairwise(r, r, n);
+        counter++;
+    }
+    for (int i = 0; i < n; ++i) y[i] = y[i] * dis[i];                    /* :864 */
+    free(dis); free(r); free(p); free(tmp);
+    return counter;
+}
+
 /* ------------------------------------------------------------------ */
 /* CSR SpMV y = A x (sequential, ascending columns inside a row).        */
 /* ------------------------------------------------------------------ */

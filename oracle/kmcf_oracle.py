@@ -153,6 +153,32 @@ def assemble_K(ks, element, charge, metals, high_G, low_G, Vd, P=1):
     return dict(val=val, diag=diag, dinv=dinv, rhs=rhs, left=left, right=right)
 
 
+def update_CB_edge(ks, element, metals, high_G, low_G, Vd, x0=None, tol=1e-14, max_it=50000):
+    """update_CB_edge_gpu_sparse (src/potential_solver_gpu.cu:673-772): returns (site_CB_edge[N] in J,
+    iterations, scaled A values, scaled rhs)."""
+    L = lib()
+    L.orc_assemble_CB.argtypes = [_ip, _ip, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                  _ip, _ip, _dp, _ip, _ip, _ip, _ip, _dp]
+    L.orc_solve_sparse_CG_Jacobi.restype = C.c_int
+    L.orc_solve_sparse_CG_Jacobi.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, C.c_double, C.c_int]
+    n = ks.n
+    val = np.zeros(ks.nnz)
+    rhs = np.zeros(n)
+    lc = _i(ks.left_col) if len(ks.left_col) else np.zeros(1, np.int32)
+    rc = _i(ks.right_col) if len(ks.right_col) else np.zeros(1, np.int32)
+    L.orc_assemble_CB(_i(element), _i(metals), len(metals), high_G, low_G, Vd, ks.N_left, n,
+                      ks.row_ptr, ks.col, val, _i(ks.left_row_ptr), lc, _i(ks.right_row_ptr), rc, rhs)
+    val_unscaled, rhs_unscaled = val.copy(), rhs.copy()
+    y = np.zeros(n) if x0 is None else _f(x0).copy()
+    it = L.orc_solve_sparse_CG_Jacobi(n, ks.row_ptr, ks.col, val, rhs, y, tol, max_it)
+    eV_to_J = 1.60217663e-19                                   # potential_solver_gpu.cu:6
+    out = np.empty(ks.N)
+    out[:ks.N_left] = Vd / 2                                    # :746-749
+    out[ks.N_left:ks.N_left + n] = y
+    out[ks.N_left + n:] = -Vd / 2
+    return out * eV_to_J, it, dict(val=val_unscaled, rhs=rhs_unscaled, val_scaled=val, rhs_scaled=rhs)
+
+
 def spmv(row_ptr, col, val, x, omp=False):
     n = len(row_ptr) - 1
     y = np.zeros(n)

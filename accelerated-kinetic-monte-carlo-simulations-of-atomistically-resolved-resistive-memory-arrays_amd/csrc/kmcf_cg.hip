@@ -267,11 +267,196 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     return KMCF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-reduction PCG (Chronopoulos & Gear): the same Krylov iterates in exact arithmetic, but both
+// inner products of an iteration -- gamma = (r,z) and delta = (Az,z) -- are available at the same
+// point, so a multi-rank group pays ONE all-reduce (of 3 doubles) per iteration instead of two, and an
+// iteration is 2 kernels (SpMV with fused delta | fused vector update) instead of 3.  The matrix is
+// applied to z = M^-1 r; s = A p is carried by recurrence.  Same stopping rule on gamma / (b.b).
+// Default for groups of more than one rank (latency-bound there); KMCF_CG_VARIANT=classic|cg1r overrides.
+//
+//   init : r = b - A x0 ; z = r.*dinv ; gamma = (r,z)
+//   loop : w = A z ; delta = (w,z) ; [all-reduce gamma, delta]
+//          stop if !(gamma/bb > tol^2)
+//          beta = gamma/gamma_old (0 first) ; alpha = gamma / (delta - beta*gamma/alpha_old)
+//          p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = r.*dinv ; gamma' = (r,z)
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg1_init_kernel(int n, double *__restrict__ r, const double *__restrict__ Ap,
+                                                              const double *__restrict__ dinv, double *__restrict__ z_out,
+                                                              double *__restrict__ part_rz, double *__restrict__ part_bb)
+{
+    __shared__ double lds4[4];
+    double rz = 0.0, bb = 0.0;
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+        double b = r[i];
+        bb += b * b;
+        double ri = b + (-1.0) * Ap[i];
+        r[i] = ri;
+        double z = PRECOND ? ri * dinv[i] : ri;
+        z_out[i] = z;
+        rz += ri * z;
+    }
+    double t = block_sum(rz, lds4);
+    double u = block_sum(bb, lds4);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = t; part_bb[blockIdx.x] = u; }
+}
+
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
+    int n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p, double *__restrict__ s,
+    double *__restrict__ z /* in: z, out: next z (SpMV input) */, const double *__restrict__ w,
+    const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta, part_ref pbb, kmcf_scalars *__restrict__ S,
+    int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz)
+{
+    __shared__ double lds4[4];
+    if (S->done) return;
+    const double gamma = reduce_partials(pgamma.a, pgamma.na, pgamma.b, pgamma.nb, lds4);
+    const double delta = reduce_partials(pdelta.a, pdelta.na, pdelta.b, pdelta.nb, lds4);
+    double bb;
+    if (first) bb = reduce_partials(pbb.a, pbb.na, pbb.b, pbb.nb, lds4);
+    else bb = S->bb;
+    const bool go = check_tol ? (gamma / bb > tol2) : true;
+    double beta = 0.0, alpha;
+    if (first) {
+        alpha = gamma / delta;
+    } else {
+        beta = gamma / S->rz[parity ^ 1];
+        alpha = gamma / (delta - beta * gamma / S->alpha[parity ^ 1]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->rz_last = gamma;
+        if (first) S->bb = bb;
+        if (go) { S->rz[parity] = gamma; S->alpha[parity] = alpha; S->pAp = delta; S->iters += 1; }
+        else S->done = 1;
+    }
+    if (!go) return;
+    const double na = -alpha;
+    double rz = 0.0;
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+        const double zi = z[i], wi = w[i];
+        const double pi = first ? zi : zi + beta * p[i];
+        const double si = first ? wi : wi + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] = x[i] + alpha * pi;
+        const double ri = r[i] + na * si;
+        r[i] = ri;
+        const double zn = PRECOND ? ri * dinv[i] : ri;
+        z[i] = zn;
+        rz += ri * zn;
+    }
+    double t = block_sum(rz, lds4);
+    if (threadIdx.x == 0) part_rz[blockIdx.x] = t;
+}
+
+// 1-block finalize for the multi-rank case: red[0] = gamma, red[1] = delta, red[2] = bb partial (first only)
+__global__ __launch_bounds__(KMCF_BLOCK) void cg1_finalize_kernel(part_ref pg, part_ref pd, part_ref pb, int first,
+                                                                  kmcf_scalars *__restrict__ S)
+{
+    __shared__ double lds4[4];
+    if (S->done) return;
+    double g = reduce_partials(pg.a, pg.na, pg.b, pg.nb, lds4);
+    double d = reduce_partials(pd.a, pd.na, pd.b, pd.nb, lds4);
+    double b = first ? reduce_partials(pb.a, pb.na, pb.b, pb.nb, lds4) : 0.0;
+    if (threadIdx.x == 0) { S->red[0] = g; S->red[1] = d; S->red[2] = b; }
+}
+
+template <bool PRECOND>
+int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
+{
+    kmcf_comm *c = m->comm;
+    hipStream_t st = c->stream;
+    const int n = m->n_loc;
+    const int vg = vec_grid(n);
+    const bool multi = c->nranks > 1 || c->force_collectives;
+    kmcf_scalars *S = m->d_S;
+    const double tol2 = tol * tol;
+    const int check_tol = fixed_iters > 0 ? 0 : 1;
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    if (!m->d_pd) {
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_pd), ((size_t)n + 2) * sizeof(double)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_s), ((size_t)n + 2) * sizeof(double)));
+    }
+    part_ref pg_loc{m->d_part_b, vg, nullptr, 0};
+    part_ref pb_loc{m->d_part_c, vg, nullptr, 0};
+    part_ref pd_loc{m->d_part_a, m->spmv_grid, m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
+    part_ref pg = multi ? part_ref{&S->red[0], 1, nullptr, 0} : pg_loc;
+    part_ref pd = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pd_loc;
+    part_ref pb = multi ? part_ref{&S->red[2], 1, nullptr, 0} : pb_loc;
+
+    KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
+    KMCF_HIP(hipEventRecord(c->ev_t0, st));
+    KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    KMCF_TRY(kmcf_spmv_device(m, false, false));                       // A x0
+    cg1_init_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, m->d_p, m->d_part_b, m->d_part_c);
+    KMCF_HIP(hipGetLastError());
+
+    int launched = 0;
+    bool done = false;
+    while (launched < limit && !done) {
+        int chunk = limit - launched;
+        if (chunk > KMCF_CHUNK_ITERS) chunk = KMCF_CHUNK_ITERS;
+        for (int i = 0; i < chunk; ++i) {
+            const int k = launched + i + 1;
+            const int parity = k & 1, first = (k == 1) ? 1 : 0;
+            KMCF_TRY(kmcf_spmv_device(m, true, true));                 // w = A z, delta partials
+            if (multi) {
+                cg1_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg_loc, pd_loc, pb_loc, first, S);
+                KMCF_HIP(hipGetLastError());
+                KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 3));
+            }
+            cg1_update_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap,
+                                                                  m->d_dinv, pg, pd, pb, S, parity, first, tol2,
+                                                                  check_tol, m->d_part_b);
+            KMCF_HIP(hipGetLastError());
+        }
+        launched += chunk;
+        if (check_tol) {
+            KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            KMCF_HIP(hipStreamSynchronize(st));
+            done = c->h_pinned[0] != 0;
+        }
+    }
+    if (!done) {   // r.z after the last iteration, for the printed residual
+        if (multi) {
+            cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg_loc, 0, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+            KMCF_HIP(hipGetLastError());
+            KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 1));
+        }
+        cg_tail_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg, S);
+        KMCF_HIP(hipGetLastError());
+    }
+    KMCF_HIP(hipEventRecord(c->ev_t1, st));
+    kmcf_scalars hS;
+    KMCF_HIP(hipMemcpyAsync(&hS, S, sizeof(hS), hipMemcpyDeviceToHost, st));
+    KMCF_HIP(hipStreamSynchronize(st));
+    if (multi) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    if (stats) {
+        stats->iterations = hS.iters;
+        stats->bb = hS.bb;
+        stats->rz = hS.rz_last;
+        stats->relres = std::sqrt(hS.rz_last / hS.bb);
+        stats->converged = (hS.done != 0) || !(hS.rz_last / hS.bb > tol2);
+        float ms = 0.f;
+        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        stats->ms_solve = ms;
+    }
+    return KMCF_OK;
+}
+
 }  // namespace
 
 // Solve on the matrix workspace: m->d_r holds b, m->d_x the start guess, m->d_dinv 1/diag.
 int kmcf_pcg_workspace(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
 {
+    // classic = the reference's recurrence and operation order (default for one rank);
+    // cg1r = single-reduction variant (default for multi-rank groups)
+    bool cg1r = m->comm->nranks > 1;
+    if (const char *e = getenv("KMCF_CG_VARIANT")) cg1r = (e[0] == 'c' && e[1] == 'g');
+    if (cg1r) {
+        if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats);
+        return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats);
+    }
     if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats);
     return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats);
 }

@@ -49,6 +49,7 @@ struct kmcf_scalars {
     double rz_last;   // most recent r.z
     double pAp;
     double red[4];    // all-reduce staging (multi-rank)
+    double alpha[2];  // single-reduction CG: step length ping-pong by iteration parity
     int done;         // stopping rule met
     int iters;        // iterations executed
     int pad[2];
@@ -132,6 +133,8 @@ struct kmcf_matrix {
     double *d_r = nullptr;
     double *d_x = nullptr;
     double *d_dinv = nullptr;
+    double *d_pd = nullptr;            // single-reduction CG: search direction p (d_p then carries z)
+    double *d_s = nullptr;             // single-reduction CG: s = A p by recurrence
     double *d_part_a = nullptr;        // KMCF_MAX_PARTIALS x 2 (pAp partials)
     double *d_part_b = nullptr;        // rz partials
     double *d_part_c = nullptr;        // bb partials

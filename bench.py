@@ -57,7 +57,8 @@ def main():
     if args.workload == "40nm":
         d = km.structure.synth_crossbar_40nm()
     elif args.workload == "small":
-        d = km.structure.synth_small(tiles=2)
+        # about one eighth of the 40 nm workload: what one rank holds in the 8-GPU run
+        d = km.structure.synth_crossbar_40nm(tiles=3, n_lines=1)
     else:
         d = km.structure.load_device_5nm("init")
     NL = d["N_contact"]

@@ -278,3 +278,39 @@ def test_total_potential_against_reference_snapshot(km, sys5, ref5):
     err = np.abs(tot[idx] - d["potential_snap6"][idx])[same]
     assert same.sum() == 36482
     assert np.median(err) <= 1e-5 and np.percentile(err, 90) <= 1e-3, (np.median(err), np.percentile(err, 90))
+
+
+def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle):
+    """KMCF_CG_VARIANT=cg1r (Chronopoulos-Gear, the default of multi-rank groups): same Krylov iterates in
+    exact arithmetic, one fused reduction per iteration.  Same stopping rule, same bars as the classic loop."""
+    import os
+    torch = torch_cuda
+    S = km.solvers
+    buf, d = sys5["buf"], sys5["d"]
+    buf.site_charge.copy_(buf.site_charge.new_tensor(ref5["charge"]))
+    S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
+    A, ks = ref5["A"], ref5["ks"]
+    os.environ["KMCF_CG_VARIANT"] = "cg1r"
+    try:
+        r = torch.as_tensor(A["rhs"], device="cuda").clone()
+        x = torch.zeros_like(r)
+        dinv = torch.as_tensor(A["dinv"], device="cuda")
+        st = S.conjugate_gradient_jacobi(mat, r, x, dinv, ref5["tol"], 10000)
+        r40 = torch.as_tensor(A["rhs"], device="cuda").clone()
+        x40 = torch.zeros_like(r40)
+        st40 = S.conjugate_gradient_jacobi(mat, r40, x40, dinv, ref5["tol"], 40)
+    finally:
+        del os.environ["KMCF_CG_VARIANT"]
+    assert st["converged"] == 1 and st["relres"] <= ref5["tol"]
+    assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"], (st["iterations"], ref5["iters"])
+    xg = x.cpu().numpy()
+    dx = np.abs(xg - ref5["x"])
+    assert dx.max() <= 5e-4 and np.median(dx) <= 5e-6, (dx.max(), np.median(dx))
+    res = A["rhs"] - oracle.spmv(ks.row_ptr, ks.col, A["val"], xg)
+    assert np.linalg.norm(res) / np.linalg.norm(A["rhs"]) <= 2e-9
+    # equal iteration count, early: the two recurrences still agree closely
+    xo, ito, relo = oracle.pcg_jacobi(ks.row_ptr, ks.col, A["val"], A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"], 40)
+    assert st40["iterations"] == 40 and st40["converged"] == 0
+    assert np.abs(x40.cpu().numpy() - xo).max() <= 1e-7
+    np.testing.assert_allclose(st40["relres"], relo, rtol=1e-4)

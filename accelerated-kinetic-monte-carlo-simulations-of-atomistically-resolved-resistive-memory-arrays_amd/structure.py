@@ -57,6 +57,25 @@ def read_parameters(path):
     return out
 
 
+def load_csr_binaries(directory, matrix_size, nnz, suffix=""):
+    """The authors' benchmark matrix format (dist_iterative_test/utils.cpp:25-56, main_test_cg.cpp:
+    140-170): raw host-endian arrays A_data<suffix>.bin (f64), A_row_ptr<suffix>.bin,
+    A_col_indices<suffix>.bin (i32), A_rhs<suffix>.bin and optionally solution<suffix>.bin (f64)."""
+    def rd(name, dtype, count, required=True):
+        path = os.path.join(directory, name + suffix + ".bin")
+        if not os.path.exists(path):
+            if required:
+                raise FileNotFoundError(path)
+            return None
+        a = np.fromfile(path, dtype=dtype, count=count)
+        if len(a) != count:
+            raise ValueError("%s: expected %d entries, found %d" % (path, count, len(a)))
+        return a
+    return dict(data=rd("A_data", np.float64, nnz), row_ptr=rd("A_row_ptr", np.int32, matrix_size + 1),
+                col_indices=rd("A_col_indices", np.int32, nnz), rhs=rd("A_rhs", np.float64, matrix_size),
+                solution=rd("solution", np.float64, matrix_size, required=False))
+
+
 def load_device_5nm(state="init"):
     """dict(xyz, element, lattice, N, N_contact, metals, Vd, nn_dist, ...) of the 5 nm example.
     state: 'file' (as in reordered_device_5.xyz), 'init' (after makeSubstoichiometric: 400 V)

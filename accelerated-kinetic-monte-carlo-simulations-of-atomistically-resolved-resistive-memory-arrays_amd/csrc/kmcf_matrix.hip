@@ -249,6 +249,52 @@ extern "C" int kmcf_matrix_create_csr(kmcf_comm *c, int matrix_size, const int *
     return kmcf_matrix_build(c, matrix_size, h_counts, h_displs, h_row_ptr, h_col_global, h_val, nullptr, out);
 }
 
+// "Split sparse" operator of the T-matrix path: A = A_neighbour + P^T A_sub P, where A_sub acts on the
+// sub-vector of the `subblock_size` tunnel rows of ALL ranks (conjugate_gradient_jacobi_split_sparse +
+// dspmv_split_sparse::spmm_split_sparse1/2/3, dist_iterative/dist_conjugate_gradient_split_sparse.cpp:18-182,
+// dist_spmv_split_sparse.cpp; Distributed_subblock_sparse, dist_objects.h:52-65).  The reference keeps the
+// two pieces apart and all-gathers the sub-vector on every SpMV (ring Isend/Irecv or MPI_Iallgatherv);
+// here the sub-block is merged into the row-partitioned CSR at build time, so its off-rank columns simply
+// become halo columns of the one compact-halo SpMV and the PCG entry points are the ordinary ones.
+// h_sub_global_rows[s] = global row of sub index s (the reference all-gathers these once,
+// src/initialize_sparsity_T.cu:752-786); this rank owns sub indices [displ_sub[rank], +count_sub[rank]).
+// h_sub_col holds GLOBAL sub indices.  Duplicate (row, col) pairs of the two pieces are kept as two entries.
+extern "C" int kmcf_matrix_create_split_sparse(kmcf_comm *c, int matrix_size, const int *h_counts, const int *h_displs,
+                                               const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                                               int subblock_size, const int *h_count_sub, const int *h_displ_sub,
+                                               const int *h_sub_global_rows, const int *h_sub_row_ptr,
+                                               const int *h_sub_col, const double *h_sub_val, kmcf_matrix **out)
+{
+    KMCF_CHECK(c && h_counts && h_displs && h_row_ptr && h_count_sub && h_displ_sub && h_sub_global_rows && h_sub_row_ptr && out,
+               KMCF_ERR_ARG, "kmcf_matrix_create_split_sparse: null argument");
+    const int rank = c->rank, n_loc = h_counts[rank], row0 = h_displs[rank];
+    const int ns_loc = h_count_sub[rank], s0 = h_displ_sub[rank];
+    KMCF_CHECK(s0 >= 0 && s0 + ns_loc <= subblock_size, KMCF_ERR_ARG, "kmcf_matrix_create_split_sparse: sub-block partition out of range");
+    // extra entries per local row
+    std::vector<int> extra((size_t)n_loc, 0);
+    for (int s = 0; s < ns_loc; ++s) {
+        const int r = h_sub_global_rows[s0 + s] - row0;
+        KMCF_CHECK(r >= 0 && r < n_loc, KMCF_ERR_ARG, "kmcf_matrix_create_split_sparse: sub index %d maps to row %d outside this rank", s0 + s, r + row0);
+        extra[r] += h_sub_row_ptr[s + 1] - h_sub_row_ptr[s];
+    }
+    std::vector<int> rp((size_t)n_loc + 1, 0);
+    for (int r = 0; r < n_loc; ++r) rp[r + 1] = rp[r] + (h_row_ptr[r + 1] - h_row_ptr[r]) + extra[r];
+    std::vector<int> col((size_t)rp[n_loc]);
+    std::vector<double> val((size_t)rp[n_loc]);
+    std::vector<int> fill(rp.begin(), rp.end() - 1);
+    for (int r = 0; r < n_loc; ++r)
+        for (int j = h_row_ptr[r]; j < h_row_ptr[r + 1]; ++j) { col[fill[r]] = h_col_global[j]; val[fill[r]++] = h_val ? h_val[j] : 0.0; }
+    for (int s = 0; s < ns_loc; ++s) {
+        const int r = h_sub_global_rows[s0 + s] - row0;
+        for (int j = h_sub_row_ptr[s]; j < h_sub_row_ptr[s + 1]; ++j) {
+            KMCF_CHECK(h_sub_col[j] >= 0 && h_sub_col[j] < subblock_size, KMCF_ERR_ARG, "kmcf_matrix_create_split_sparse: sub column out of range");
+            col[fill[r]] = h_sub_global_rows[h_sub_col[j]];
+            val[fill[r]++] = h_sub_val ? h_sub_val[j] : 0.0;
+        }
+    }
+    return kmcf_matrix_build(c, matrix_size, h_counts, h_displs, rp.data(), col.data(), val.data(), nullptr, out);
+}
+
 extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
 {
     if (!m) return KMCF_OK;

@@ -306,6 +306,27 @@ class Distributed_matrix:
         self.handle = h
 
     @classmethod
+    def split_sparse(cls, kmc_comm, matrix_size, counts, displacements, col_indices_in, row_ptr_in, data_in,
+                     subblock_size, count_subblock, displ_subblock, subblock_global_rows,
+                     sub_row_ptr, sub_col_indices, sub_data):
+        """Distributed_matrix + Distributed_subblock_sparse (dist_objects.h:52-65): the operator
+        A_neighbour + P^T A_sub P of conjugate_gradient_jacobi_split_sparse, merged at build time."""
+        self = cls.__new__(cls)
+        self.lib = _L.load()
+        self.owned = True
+        h = C.c_void_p()
+        a = [_ia(v) for v in (counts, displacements, row_ptr_in, col_indices_in, count_subblock, displ_subblock,
+                              subblock_global_rows, sub_row_ptr, sub_col_indices)]
+        dv, dp = _da(data_in)
+        sv, sp_ = _da(sub_data)
+        _L.check(self.lib.kmcf_matrix_create_split_sparse(kmc_comm.handle, int(matrix_size), a[0][1], a[1][1], a[2][1],
+                                                          a[3][1], dp, int(subblock_size), a[4][1], a[5][1], a[6][1],
+                                                          a[7][1], a[8][1], sp_, C.byref(h)),
+                 "kmcf_matrix_create_split_sparse")
+        self.handle = h
+        return self
+
+    @classmethod
     def from_handle(cls, handle):
         self = cls.__new__(cls)
         self.lib = _L.load()

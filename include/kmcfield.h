@@ -78,6 +78,21 @@ int kmcf_matrix_create_csr(kmcf_comm *c, int matrix_size, const int *h_counts, c
                            kmcf_matrix **out);
 int kmcf_matrix_destroy(kmcf_matrix *m);
 
+/* "Split sparse" operator of the T-matrix path, A = A_neighbour + P^T A_sub P
+ * (conjugate_gradient_jacobi_split_sparse + dspmv_split_sparse::spmm_split_sparse1/2/3,
+ * dist_iterative/dist_conjugate_gradient_split_sparse.cpp:18-182, dist_spmv_split_sparse.cpp;
+ * Distributed_subblock_sparse, dist_objects.h:52-65).  The sub-block (rows = this rank's
+ * count_sub[rank] tunnel rows, columns = GLOBAL sub indices 0..subblock_size) is merged into
+ * the row-partitioned CSR at build time; kmcf_spmv / kmcf_pcg_jacobi then apply as usual
+ * (no per-SpMV all-gather of the sub-vector).  h_sub_global_rows[s] = global matrix row of
+ * sub index s for ALL ranks (the reference all-gathers them once,
+ * src/initialize_sparsity_T.cu:752-786). */
+int kmcf_matrix_create_split_sparse(kmcf_comm *c, int matrix_size, const int *h_counts, const int *h_displs,
+                                    const int *h_row_ptr, const int *h_col_global, const double *h_val,
+                                    int subblock_size, const int *h_count_sub, const int *h_displ_sub,
+                                    const int *h_sub_global_rows, const int *h_sub_row_ptr,
+                                    const int *h_sub_col, const double *h_sub_val, kmcf_matrix **out);
+
 typedef struct {
     int matrix_size;          /* global rows                                        */
     int rows_this_rank;

@@ -1,0 +1,279 @@
+// KMC event step: residence-time selection over the (site, neighbour) event list.
+// Replaces execute_kmc_step_mpi (src/kmc_events.cu:333-563) and its kernels build_event_list_split
+// (:128-207), zero_out_events_split (:237-256), read_out_event (:257-269), execute_event (:284-331).
+//
+// Reference per EVENT: thrust::inclusive_scan over all count*nn slots (16 B/slot read + 8 B/slot written),
+// a device upper_bound, a full zero-out pass.  Here the list keeps one partial sum per 2048-slot block:
+//   per step : build kernel (type u8 + probability f64 per slot) + block sums
+//   per event: total = fixed-order sum of the block sums (1 block) -> host draws -> select kernel walks the
+//              block sums, then the slots of ONE block -> execute -> zero-out pass that also refreshes the
+//              block sums (one read of neigh/prob per event, no scan array at all).
+// Same selection rule (first slot whose inclusive cumulative sum exceeds u * total), same event rules,
+// same loop (events are drawn until the LAST drawn residence time reaches 1/freq; that last draw is the
+// returned time).  Ranks own contiguous site ranges; the partial totals are all-gathered and the rank
+// whose range holds the drawn number selects (MPI_Allgather + MPI_Bcast in the reference, :423-470).
+#include <cmath>
+#include <random>
+#include <vector>
+
+#include "kmcf_internal.hpp"
+
+struct kmcf_rng {
+    std::mt19937 rng{0};                                            // src/random_num.h
+    std::uniform_real_distribution<double> distribution{0.0, 1.0};
+};
+
+extern "C" int kmcf_rng_create(unsigned int seed, kmcf_rng **out)
+{
+    KMCF_CHECK(out, KMCF_ERR_ARG, "kmcf_rng_create: null argument");
+    kmcf_rng *r = new kmcf_rng();
+    r->rng.seed(seed);                                              // RandomNumberGenerator::setSeed
+    *out = r;
+    return KMCF_OK;
+}
+
+extern "C" double kmcf_rng_next(void *rng) { kmcf_rng *r = static_cast<kmcf_rng *>(rng); return r->distribution(r->rng); }
+
+extern "C" int kmcf_rng_destroy(kmcf_rng *r) { delete r; return KMCF_OK; }
+
+namespace {
+
+constexpr int EL_DEFECT = 0, EL_OXYGEN_DEFECT = 1, EL_VACANCY = 2, EL_O = 3;       // src/utils.h:37-44
+constexpr int EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_ODIFF = 3, EV_NULL = 4;     // EVENTTYPE, src/utils.h:53-60
+constexpr int EV_TILE = 2048;                                                       // slots per block sum
+constexpr int MAX_LAYERS = 8;
+
+struct layer_energies { double gen[MAX_LAYERS], rec[MAX_LAYERS], vdiff[MAX_LAYERS], odiff[MAX_LAYERS]; };
+
+__device__ __forceinline__ double v_solve_dev(double r_dist, int charge, double sigma, double k)
+{
+    const double q = 1.60217663e-19;                                // src/gpu_solvers.h:321-329
+    return (double)charge * erfc(r_dist / (sigma * sqrt(2.0))) * k * q / r_dist;
+}
+
+__device__ __forceinline__ double block_sum_ev(double v, double *lds4)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    __syncthreads();
+    return t;
+}
+
+// build_event_list_split, src/kmc_events.cu:128-207
+__global__ __launch_bounds__(KMCF_BLOCK) void build_event_list_kernel(
+    int N, int size_i, int start_i, int nn, const int *__restrict__ neigh_idx, const int *__restrict__ layer,
+    double T_bg, double freq, double sigma, double k, const double *__restrict__ x, const double *__restrict__ y,
+    const double *__restrict__ z, const double *__restrict__ pot, const int *__restrict__ element,
+    const int *__restrict__ charge, layer_energies E, unsigned char *__restrict__ event_type,
+    double *__restrict__ event_prob)
+{
+    const double kB = 8.617333262e-5, epsilon = 1e-200;
+    const size_t M = (size_t)size_i * nn;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < M; id += (size_t)gridDim.x * blockDim.x) {
+        int et = EV_NULL;
+        double P = 0.0;
+        const int i = (int)(id / nn) + start_i;
+        const int j = neigh_idx[id];
+        if (j >= 0 && j < N) {
+            const double dx = x[j] - x[i], dy = y[j] - y[i], dz = z[j] - z[i];
+            const double dist = 1e-10 * sqrt(dx * dx + dy * dy + dz * dz);
+            const int ei = element[i], ej = element[j];
+            const double dpot = pot[i] - pot[j];
+            double EA = 0.0;
+            if (ei == EL_DEFECT && ej == EL_O) {
+                const double Eg = 2 * dpot;
+                EA = E.gen[layer[j]] - Eg - 0;
+                et = EV_GEN;
+            }
+            if (ei == EL_OXYGEN_DEFECT && ej == EL_VACANCY) {
+                const double self_int_V = v_solve_dev(dist, 2, sigma, k);
+                const int charge_state = charge[i] - charge[j];
+                const double Er = charge_state * (dpot + (charge_state / 2) * self_int_V);
+                EA = E.rec[layer[j]] - Er - 0;
+                et = EV_REC;
+            }
+            if (ei == EL_VACANCY && ej == EL_O) {
+                double self_int_V = 0.0;
+                if (charge[i] != 0) self_int_V = v_solve_dev(dist, charge[i], sigma, k);
+                const double Ev = (charge[i] - charge[j]) * (dpot + self_int_V);
+                EA = E.vdiff[layer[j]] - Ev - 0;
+                et = EV_VDIFF;
+            }
+            if (ei == EL_OXYGEN_DEFECT && ej == EL_DEFECT) {
+                double self_int_V = 0.0;
+                if (charge[i] != 0) self_int_V = v_solve_dev(dist, 2, sigma, k);
+                const double Eo = (charge[i] - charge[j]) * (dpot - self_int_V);
+                EA = E.odiff[layer[j]] - Eo - 0;
+                et = EV_ODIFF;
+            }
+            if (et != EV_NULL) P = freq * (1 / (exp(EA / (kB * T_bg)) + epsilon));
+        }
+        event_type[id] = (unsigned char)et;
+        event_prob[id] = P;
+    }
+}
+
+// Zero the events touching the executed pair (zero_out_events_split, :237-256) and refresh the block sum.
+// i_del < 0: plain block sums (first call of a step).
+__global__ __launch_bounds__(KMCF_BLOCK) void zero_and_sum_kernel(size_t M, int start_i, int nn,
+                                                                  const int *__restrict__ neigh_idx,
+                                                                  unsigned char *__restrict__ event_type,
+                                                                  double *__restrict__ event_prob, int i_del, int j_del,
+                                                                  double *__restrict__ bsum)
+{
+    __shared__ double lds4[4];
+    const size_t base = (size_t)blockIdx.x * EV_TILE;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < EV_TILE; t += KMCF_BLOCK) {
+        const size_t id = base + t;
+        if (id >= M) break;
+        double p = event_prob[id];
+        if (i_del >= 0) {
+            const int i = (int)(id / nn) + start_i, j = neigh_idx[id];
+            if (j >= 0 && (i == i_del || j == j_del || i == j_del || j == i_del)) {
+                event_type[id] = (unsigned char)EV_NULL;
+                event_prob[id] = 0.0;
+                p = 0.0;
+            }
+        }
+        s += p;
+    }
+    const double tot = block_sum_ev(s, lds4);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// total = sum of the block sums, fixed order
+__global__ __launch_bounds__(KMCF_BLOCK) void total_kernel(int nb, const double *__restrict__ bsum, double *__restrict__ total)
+{
+    __shared__ double lds4[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += KMCF_BLOCK) s += bsum[b];
+    const double t = block_sum_ev(s, lds4);
+    if (threadIdx.x == 0) *total = t;
+}
+
+// First slot whose inclusive cumulative sum exceeds `number` (thrust::upper_bound on the scan, :444).
+// One wave: sequential walk over the block sums, then over the slots of the block that holds the number.
+__global__ void select_event_kernel(size_t M, int nb, int start_i, int nn, double number, const double *__restrict__ bsum,
+                                    const double *__restrict__ event_prob, const unsigned char *__restrict__ event_type,
+                                    const int *__restrict__ neigh_idx, int *__restrict__ ijevent)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double acc = 0.0;
+    int b = 0;
+    while (b + 1 < nb && !(number < acc + bsum[b])) { acc += bsum[b]; ++b; }
+    size_t id = (size_t)b * EV_TILE;
+    const size_t e = id + EV_TILE < M ? id + EV_TILE : M;
+    double c = acc;
+    for (; id < e; ++id) { c += event_prob[id]; if (number < c) break; }
+    if (id >= M) id = M - 1;
+    ijevent[0] = (int)(id / nn) + start_i;
+    ijevent[1] = neigh_idx[id];
+    ijevent[2] = (int)event_type[id];
+}
+
+// execute_event, :284-331
+__global__ void execute_event_kernel(int *__restrict__ site_element, int *__restrict__ site_charge, const int *__restrict__ ijevent)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int i = ijevent[0], j = ijevent[1], et = ijevent[2];
+    if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
+    else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
+    else if (et == EV_VDIFF || et == EV_ODIFF) {
+        const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
+        const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+    }
+}
+
+}  // namespace
+
+extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, const int *h_displs, int nn,
+                                     const int *d_neigh_idx, const int *d_site_layer, double T_bg, double freq,
+                                     double sigma, double k, const double *d_x, const double *d_y, const double *d_z,
+                                     const double *d_site_potential_charge, int *d_site_element, int *d_site_charge,
+                                     int num_layers, const double *h_E_gen, const double *h_E_rec,
+                                     const double *h_E_Vdiff, const double *h_E_Odiff,
+                                     double (*next_random)(void *), void *rng_user, int max_events,
+                                     double *event_time, int *n_events, int *h_event_log)
+{
+    KMCF_CHECK(c && h_count && h_displs && d_neigh_idx && d_site_layer && d_x && d_y && d_z && d_site_potential_charge &&
+                   d_site_element && d_site_charge && h_E_gen && h_E_rec && h_E_Vdiff && h_E_Odiff && next_random && event_time,
+               KMCF_ERR_ARG, "kmcf_execute_kmc_step: null argument");
+    KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_execute_kmc_step: host-only communicator");
+    KMCF_CHECK(num_layers > 0 && num_layers <= MAX_LAYERS && nn > 0 && freq > 0, KMCF_ERR_ARG, "kmcf_execute_kmc_step: bad sizes");
+    KMCF_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int P = c->nranks, rank = c->rank;
+    const int count = h_count[rank], start_i = h_displs[rank];
+    const size_t M = (size_t)count * nn;
+    const int nb = (int)((M + EV_TILE - 1) / EV_TILE);
+    layer_energies E;
+    for (int l = 0; l < MAX_LAYERS; ++l) {
+        E.gen[l] = l < num_layers ? h_E_gen[l] : 0.0; E.rec[l] = l < num_layers ? h_E_rec[l] : 0.0;
+        E.vdiff[l] = l < num_layers ? h_E_Vdiff[l] : 0.0; E.odiff[l] = l < num_layers ? h_E_Odiff[l] : 0.0;
+    }
+    unsigned char *d_type = nullptr;
+    double *d_prob = nullptr, *d_bsum = nullptr, *d_tot = nullptr;
+    int *d_ij = nullptr;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_type), std::max<size_t>(M, 1)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_prob), std::max<size_t>(M, 1) * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_bsum), (size_t)std::max(nb, 1) * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_tot), (size_t)P * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_ij), (size_t)3 * P * sizeof(int)));
+    std::vector<int> ones(P, 1), iota(P), threes(P, 3), iota3(P);
+    for (int q = 0; q < P; ++q) { iota[q] = q; iota3[q] = 3 * q; }
+    int rc = KMCF_OK;
+    auto fail = [&](int code) { rc = code; };
+    if (M > 0) {
+        int64_t g = ((int64_t)M + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
+        if (g > 16384) g = 16384;
+        build_event_list_kernel<<<(int)g, KMCF_BLOCK, 0, st>>>(N, count, start_i, nn, d_neigh_idx, d_site_layer, T_bg, freq, sigma, k,
+                                                               d_x, d_y, d_z, d_site_potential_charge, d_site_element,
+                                                               d_site_charge, E, d_type, d_prob);
+        zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, -1, -1, d_bsum);
+    }
+    double t = 0.0;
+    int nev = 0;
+    std::vector<double> totals(P);
+    while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                          // :418
+        if (M > 0) total_kernel<<<1, KMCF_BLOCK, 0, st>>>(nb, d_bsum, d_tot + rank);
+        else if (hipMemsetAsync(d_tot + rank, 0, sizeof(double), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        if (kmcf_comm_allgatherv_double(c, d_tot, ones.data(), iota.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }   // MPI_Allgather :423
+        if (hipMemcpyAsync(totals.data(), d_tot, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        for (int q = 1; q < P; ++q) totals[q] += totals[q - 1];                           // :425-427
+        const double total = totals[P - 1];
+        double number = next_random(rng_user) * total;                                    // :430
+        int source_rank = P - 1;
+        for (int q = 0; q < P; ++q)
+            if (number < totals[q]) { source_rank = q; break; }                           // :432-437
+        if (hipMemsetAsync(d_ij + 3 * rank, 0xff, 3 * sizeof(int), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        if (rank == source_rank && M > 0) {
+            if (rank > 0) number -= totals[rank - 1];                                     // :440-442
+            select_event_kernel<<<1, 64, 0, st>>>(M, nb, start_i, nn, number, d_bsum, d_prob, d_type, d_neigh_idx, d_ij + 3 * rank);
+        }
+        if (kmcf_comm_allgatherv_int(c, d_ij, threes.data(), iota3.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }     // MPI_Bcast :455-459
+        int ij[3];
+        if (hipMemcpyAsync(ij, d_ij + 3 * source_rank, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        if (ij[0] < 0 || ij[0] >= N || ij[1] < 0 || ij[1] >= N) {
+            kmcf_set_error("kmcf_execute_kmc_step: no event could be selected (total rate %g)", total);
+            fail(KMCF_ERR_STATE);
+            break;
+        }
+        execute_event_kernel<<<1, 64, 0, st>>>(d_site_element, d_site_charge, d_ij + 3 * source_rank);
+        if (M > 0) zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, ij[0], ij[1], d_bsum);
+        if (h_event_log) { h_event_log[3 * nev] = ij[0]; h_event_log[3 * nev + 1] = ij[1]; h_event_log[3 * nev + 2] = ij[2]; }
+        t = -std::log(next_random(rng_user)) / total;                                     // :479
+        ++nev;
+    }
+    if (rc == KMCF_OK && hipStreamSynchronize(st) != hipSuccess) rc = KMCF_ERR_HIP;
+    if (rc == KMCF_ERR_HIP) kmcf_set_error("kmcf_execute_kmc_step: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    hipFree(d_type); hipFree(d_prob); hipFree(d_bsum); hipFree(d_tot); hipFree(d_ij);
+    *event_time = t;
+    if (n_events) *n_events = nev;
+    return rc;
+}

@@ -81,7 +81,13 @@ SIGNATURES = {
     "kmcf_poisson_gridless": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_int, C.c_int, _P]),
     "kmcf_update_temperature_global": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_double, C.c_double]),
-    "kmcf_neighbor_list": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
+    "kmcf_rng_create": (C.c_int, [C.c_uint, C.POINTER(_P)]),
+    "kmcf_rng_next": (C.c_double, [_P]),
+    "kmcf_rng_destroy": (C.c_int, [_P]),
+    "kmcf_execute_kmc_step": (C.c_int, [_P, C.c_int, _IP, _IP, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, _P, _P, _P, _P, _P, _P, C.c_int, _DP, _DP, _DP, _DP, _P, _P,
+                                        C.c_int, _DP, _IP, _IP]),
+    "kmcf_neighbor_list":(C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
 }
 
 _lib = None

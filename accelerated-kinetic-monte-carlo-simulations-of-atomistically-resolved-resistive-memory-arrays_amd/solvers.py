@@ -247,6 +247,66 @@ def update_temperatureglobal_gpu(site_power, T_bg, N, a_coeff, b_coeff, number_s
              "kmcf_update_temperature_global")
 
 
+class RandomNumberGenerator:
+    """RandomNumberGenerator of src/random_num.h: std::mt19937 + uniform_real_distribution<double>(0, 1)."""
+
+    def __init__(self, seed=1):
+        self.lib = _L.load()
+        h = C.c_void_p()
+        _L.check(self.lib.kmcf_rng_create(int(seed), C.byref(h)), "kmcf_rng_create")
+        self.handle = h
+
+    def setSeed(self, seed):
+        self.lib.kmcf_rng_destroy(self.handle)
+        h = C.c_void_p()
+        _L.check(self.lib.kmcf_rng_create(int(seed), C.byref(h)), "kmcf_rng_create")
+        self.handle = h
+
+    def getRandomNumber(self):
+        return self.lib.kmcf_rng_next(self.handle)
+
+
+def site_layers(site_x, layers):
+    """KMCProcess::KMCProcess (src/KMCProcess.cpp:33-50): the LAST layer whose [start_x, end_x] holds x."""
+    site_x = np.asarray(site_x)
+    lay = np.full(len(site_x), 1000, np.int32)
+    for j, l in enumerate(layers):
+        lay[(l["start_x"] <= site_x) & (site_x <= l["end_x"])] = j
+    if lay.max() >= 1000:
+        raise ValueError("a site is not inside the device (KMCProcess.cpp:45-48)")
+    return lay
+
+
+def execute_kmc_step_mpi(kmc_comm, N, count, displs, nn, neigh_idx, site_layer, T_bg, freq, sigma, k, posx, posy, posz,
+                         site_potential_charge, site_element, site_charge, rng, layers, max_events=1 << 20,
+                         return_log=False):
+    """execute_kmc_step_mpi (gpu_solvers.h:250; src/kmc_events.cu:333-563).  T_bg, freq, sigma, k are host
+    scalars here.  layers: list of dicts with E_gen_0, E_rec_1, E_diff_2, E_diff_3 (copytoConstMemory).
+    Returns the event time (and, with return_log, the number of events and their (i, j, type) rows)."""
+    lib = _L.load()
+    cnt, cntp = _ia(count)
+    dsp, dspp = _ia(displs)
+    eg, egp = _da([l["E_gen_0"] for l in layers])
+    er, erp = _da([l["E_rec_1"] for l in layers])
+    ev, evp = _da([l["E_diff_2"] for l in layers])
+    eo, eop = _da([l["E_diff_3"] for l in layers])
+    t = C.c_double()
+    nev = C.c_int()
+    cap = min(int(max_events), 1 << 16) if return_log else 0
+    log = np.zeros(max(3 * cap, 1), np.int32)
+    fn = C.cast(lib.kmcf_rng_next, C.c_void_p)
+    _L.check(lib.kmcf_execute_kmc_step(kmc_comm.handle, int(N), cntp, dspp, int(nn), _ptr(neigh_idx), _ptr(site_layer),
+                                       float(T_bg), float(freq), float(sigma), float(k), _ptr(posx), _ptr(posy),
+                                       _ptr(posz), _ptr(site_potential_charge), _ptr(site_element), _ptr(site_charge),
+                                       len(layers), egp, erp, evp, eop, fn, rng.handle,
+                                       cap if return_log else int(max_events), C.byref(t), C.byref(nev),
+                                       log.ctypes.data_as(C.POINTER(C.c_int)) if return_log else None),
+             "kmcf_execute_kmc_step")
+    if return_log:
+        return t.value, nev.value, log[:3 * nev.value].reshape(-1, 3).copy()
+    return t.value
+
+
 # K-state inspection helpers used by the parity tests --------------------------------
 
 def k_assemble(gpubuf, Vd, high_G, low_G):

@@ -24,6 +24,17 @@ DEFECT, OXYGEN_DEFECT, VACANCY, O_EL, Hf_EL, Ni_EL, Ti_EL, Pt_EL, N_EL, NULL_ELE
 ELEMENT_OF = {"d": DEFECT, "Od": OXYGEN_DEFECT, "V": VACANCY, "O": O_EL, "Hf": Hf_EL, "Ni": Ni_EL,
               "Ti": Ti_EL, "Pt": Pt_EL, "N": N_EL}
 
+# KMC layers of the shipped configuration: compile-time globals of src/structure_input.h:7-48
+# (type, E_gen_0, E_rec_1, E_diff_2, E_diff_3 [eV], start_x, end_x [A]); rnd_seed_kmc = 1 (:5)
+LAYERS = [
+    dict(type="contact", E_gen_0=0.0, E_rec_1=0.0, E_diff_2=0.0, E_diff_3=0.76, start_x=-22.0, end_x=0.0),
+    dict(type="interface", E_gen_0=3.93, E_rec_1=0.0, E_diff_2=1.09, E_diff_3=0.76, start_x=0.0, end_x=3.0),
+    dict(type="oxide", E_gen_0=3.93, E_rec_1=0.0, E_diff_2=1.09, E_diff_3=0.76, start_x=3.0, end_x=48.1431),
+    dict(type="interface", E_gen_0=1.66, E_rec_1=0.0, E_diff_2=1.09, E_diff_3=0.76, start_x=48.1431, end_x=52.6431),
+    dict(type="contact", E_gen_0=1.73, E_rec_1=0.0, E_diff_2=0.0, E_diff_3=2.8, start_x=52.6431, end_x=90.0),
+]
+RND_SEED_KMC = 1
+
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN_5NM = os.path.join(_ROOT, "tests", "golden", "device_5nm.npz")
 

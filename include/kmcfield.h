@@ -245,6 +245,35 @@ int kmcf_poisson_gridless(kmcf_pairwise *p, const double *d_x, const double *d_y
                           const int *d_site_charge, double sigma, double k, int count, int displ,
                           double *d_site_potential_charge);
 
+/* ---------------------------------------------------------------------- */
+/* KMC event step                                              */
+/* ---------------------------------------------------------------------- */
+/* std::mt19937 + std::uniform_real_distribution<double>(0,1): the reference's
+ * RandomNumberGenerator (src/random_num.h).  kmcf_rng_next has the callback signature
+ * kmcf_execute_kmc_step takes, so a host program may pass its own generator instead. */
+typedef struct kmcf_rng kmcf_rng;
+int kmcf_rng_create(unsigned int seed, kmcf_rng **out);
+double kmcf_rng_next(void *rng);
+int kmcf_rng_destroy(kmcf_rng *r);
+
+/* execute_kmc_step_mpi (src/kmc_events.cu:333-563): builds the (site, neighbour) event list of
+ * this rank's sites [displs[rank], +count[rank]) (build_event_list_split :128-207), then draws
+ * events -- residence-time algorithm: first slot whose cumulative rate exceeds u*total, execute
+ * (:284-331), zero the events touching the pair (:237-256), t = -log(u')/total -- until the last
+ * drawn t reaches 1/freq; *event_time = that last t (the reference's return value), *n_events the
+ * number of executed events, h_event_log (may be NULL; 3*max_events ints) the (i, j, type) triples.
+ * d_neigh_idx: this rank's count*nn neighbour slots.  Layer energies: copytoConstMemory
+ * (src/kmc_events.cu:565-571).  T_bg, freq, sigma, k: host scalars (device scalars in the reference).
+ * ELEMENT / EVENTTYPE codes: src/utils.h:37-60.  Every rank must pass a generator in the same state. */
+int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, const int *h_displs, int nn,
+                          const int *d_neigh_idx, const int *d_site_layer, double T_bg, double freq,
+                          double sigma, double k, const double *d_x, const double *d_y, const double *d_z,
+                          const double *d_site_potential_charge, int *d_site_element, int *d_site_charge,
+                          int num_layers, const double *h_E_gen, const double *h_E_rec,
+                          const double *h_E_Vdiff, const double *h_E_Odiff,
+                          double (*next_random)(void *), void *rng_user, int max_events,
+                          double *event_time, int *n_events, int *h_event_log);
+
 /* update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70). */
 int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,
                                    double a_coeff, double b_coeff, double number_steps,

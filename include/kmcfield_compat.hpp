@@ -185,6 +185,47 @@ void poisson_gridless_gpu(const int num_atoms_contact, const int pbc, const int 
                                              site_potential_charge), "kmcf_poisson_gridless");
 }
 
+// src/kmc_events.cu:565-571 + 333-563.  The layer energies are kept on the host; the reference's own
+// RandomNumberGenerator is driven through a callback, so its state advances exactly as before.
+namespace kmcf_compat {
+inline std::vector<double> &layer_E(int which) { static std::vector<double> E[4]; return E[which]; }
+inline double next_random_cb(void *user) { return static_cast<RandomNumberGenerator *>(user)->getRandomNumber(); }
+}  // namespace kmcf_compat
+
+void copytoConstMemory(std::vector<double> E_gen, std::vector<double> E_rec, std::vector<double> E_Vdiff,
+                       std::vector<double> E_Odiff)
+{
+    kmcf_compat::layer_E(0) = E_gen; kmcf_compat::layer_E(1) = E_rec;
+    kmcf_compat::layer_E(2) = E_Vdiff; kmcf_compat::layer_E(3) = E_Odiff;
+}
+
+double execute_kmc_step_mpi(MPI_Comm comm, const int N, const int *count, const int *displs, const int nn,
+                            const int *neigh_idx, const int *site_layer, const double *lattice, const int pbc,
+                            const double *T_bg, const double *freq, const double *sigma, const double *k,
+                            const double *posx, const double *posy, const double *posz,
+                            const double *site_potential_charge, const double *site_temperature,
+                            ELEMENT *site_element, int *site_charge, RandomNumberGenerator &rng)
+{
+    (void)lattice; (void)pbc; (void)site_temperature;
+    double h[4];   // T_bg, freq, sigma, k are device scalars in the reference
+    const double *d[4] = {T_bg, freq, sigma, k};
+    for (int i = 0; i < 4; ++i)
+        if (hipMemcpy(&h[i], d[i], sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) std::exit(1);
+    double event_time = 0.0;
+    int n_events = 0;
+    kmcf_compat::check(kmcf_execute_kmc_step(kmcf_compat::comm_of(comm), N, count, displs, nn, neigh_idx, site_layer, h[0], h[1],
+                                             h[2], h[3], posx, posy, posz, site_potential_charge,
+                                             reinterpret_cast<int *>(site_element), site_charge,
+                                             (int)kmcf_compat::layer_E(0).size(), kmcf_compat::layer_E(0).data(),
+                                             kmcf_compat::layer_E(1).data(), kmcf_compat::layer_E(2).data(),
+                                             kmcf_compat::layer_E(3).data(), kmcf_compat::next_random_cb, &rng, 1 << 30,
+                                             &event_time, &n_events, nullptr), "kmcf_execute_kmc_step");
+    int rank = 0;
+    MPI_Comm_rank(comm, &rank);
+    if (rank == 0) std::printf("Number of KMC events: %d\nEvent time: %g\n", n_events, event_time);   // :551-554
+    return event_time;
+}
+
 // src/heat_solver_gpu.cu:53-70
 void update_temperatureglobal_gpu(const double *site_power, double *T_bg, const int N, const double a_coeff,
                                          const double b_coeff, const double number_steps, const double C_thermal,

@@ -719,6 +719,165 @@ double orc_update_temperature_global(const double *site_power, int N, double T_b
          + pow(a_coeff, (double)step) * T_bg;                              /* :47 */
 }
 
+/* ------------------------------------------------------------------ */
+/* KMC event step: execute_kmc_step_mpi,                   */
+/* src/kmc_events.cu:333-563, single rank.                               */
+/* ------------------------------------------------------------------ */
+/* std::mt19937 (seeded like rng.seed(seed), src/random_num.h:13-17) +   */
+/* std::uniform_real_distribution<double>(0,1) as libstdc++ implements   */
+/* it: generate_canonical<double,53> = (x0 + x1 * 2^32) / 2^64 from two  */
+/* 32-bit draws, clamped below 1.                                        */
+typedef struct { uint32_t mt[624]; int idx; } orc_mt19937;
+
+void orc_mt_seed(orc_mt19937 *g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+
+uint32_t orc_mt_next(orc_mt19937 *g)
+{
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+double orc_mt_uniform(orc_mt19937 *g)
+{
+    double x0 = (double)orc_mt_next(g), x1 = (double)orc_mt_next(g);
+    double r = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    return r;
+}
+
+enum { EV_VACANCY_GENERATION = 0, EV_VACANCY_RECOMBINATION = 1, EV_VACANCY_DIFFUSION = 2, EV_ION_DIFFUSION = 3, EV_NULL = 4 };
+
+static inline double v_solve(double r_dist, int charge, double sigma, double k)
+{   /* gpu_solvers.h:321-329 */
+    const double q = 1.60217663e-19;
+    return (double)charge * erfc(r_dist / (sigma * sqrt(2.0))) * k * q / r_dist;
+}
+
+/* build_event_list_split, src/kmc_events.cu:128-207 (the no-pbc distance, :152) */
+void orc_build_event_list(int N, int size_i, int start_i, int nn, const int *neigh_idx, const int *layer,
+                          double T_bg, double freq, double sigma, double k,
+                          const double *x, const double *y, const double *z, const double *pot,
+                          const int *element, const int *charge,
+                          const double *E_gen, const double *E_rec, const double *E_Vdiff, const double *E_Odiff,
+                          int *event_type, double *event_prob)
+{
+    const double kB = 8.617333262e-5, epsilon = 1e-200;
+    for (size_t id = 0; id < (size_t)size_i * nn; ++id) {
+        int et = EV_NULL;
+        double P = 0.0;
+        int i = (int)(id / nn) + start_i;
+        int j = neigh_idx[id];
+        if (j >= 0 && j < N) {
+            double dist = 1e-10 * site_dist_nopbc(x[i], y[i], z[i], x[j], y[j], z[j]);
+            if (element[i] == DEFECT && element[j] == O_EL) {
+                double E = 2 * (pot[i] - pot[j]);
+                double EA = E_gen[layer[j]] - E - 0;
+                et = EV_VACANCY_GENERATION;
+                P = freq * (1 / (exp(EA / (kB * T_bg)) + epsilon));
+            }
+            if (element[i] == OXYGEN_DEFECT && element[j] == VACANCY) {
+                double self_int_V = v_solve(dist, 2, sigma, k);
+                int charge_state = charge[i] - charge[j];
+                double E = charge_state * (pot[i] - pot[j] + (charge_state / 2) * self_int_V);
+                double EA = E_rec[layer[j]] - E - 0;
+                et = EV_VACANCY_RECOMBINATION;
+                P = freq * (1 / (exp(EA / (kB * T_bg)) + epsilon));
+            }
+            if (element[i] == VACANCY && element[j] == O_EL) {
+                double self_int_V = 0.0;
+                if (charge[i] != 0) self_int_V = v_solve(dist, charge[i], sigma, k);
+                double E = (charge[i] - charge[j]) * (pot[i] - pot[j] + self_int_V);
+                double EA = E_Vdiff[layer[j]] - E - 0;
+                et = EV_VACANCY_DIFFUSION;
+                P = freq * (1 / (exp(EA / (kB * T_bg)) + epsilon));
+            }
+            if (element[i] == OXYGEN_DEFECT && element[j] == DEFECT) {
+                double self_int_V = 0.0;
+                if (charge[i] != 0) self_int_V = v_solve(dist, 2, sigma, k);
+                double E = (charge[i] - charge[j]) * (pot[i] - pot[j] - self_int_V);
+                double EA = E_Odiff[layer[j]] - E - 0;
+                et = EV_ION_DIFFUSION;
+                P = freq * (1 / (exp(EA / (kB * T_bg)) + epsilon));
+            }
+        }
+        event_type[id] = et;
+        event_prob[id] = P;
+    }
+}
+
+/* One KMC step, execute_kmc_step_mpi (:333-563) on one rank: events are drawn until the LAST drawn
+ * residence time reaches 1/freq (:418; the returned time is that last draw, not a sum).  The cumulative
+ * sum is blocked: sequential inside blocks of `blk` slots, then over the block sums -- the blocking
+ * the library uses (the reference's thrust::inclusive_scan order is unspecified).  Returns the number
+ * of events; *event_time = last residence time; ev_log (may be NULL): (i, j, type) per event. */
+int orc_kmc_step(int N, int nn, const int *neigh_idx, const int *layer, double T_bg, double freq, double sigma, double k,
+                 const double *x, const double *y, const double *z, const double *pot,
+                 int *element, int *charge,
+                 const double *E_gen, const double *E_rec, const double *E_Vdiff, const double *E_Odiff,
+                 orc_mt19937 *rng, int blk, int max_events, double *event_time, int *ev_log)
+{
+    size_t M = (size_t)N * nn;
+    int *type = (int *)malloc(M * sizeof(int));
+    double *prob = (double *)malloc(M * sizeof(double));
+    size_t nb = (M + blk - 1) / blk;
+    double *bsum = (double *)malloc(nb * sizeof(double));
+    orc_build_event_list(N, N, 0, nn, neigh_idx, layer, T_bg, freq, sigma, k, x, y, z, pot, element, charge,
+                         E_gen, E_rec, E_Vdiff, E_Odiff, type, prob);
+    double t = 0.0;
+    int count = 0;
+    while (t < 1 / freq && count < max_events) {
+        double total = 0.0;
+        for (size_t b = 0; b < nb; ++b) {
+            double s = 0.0;
+            size_t e = (b + 1) * blk < M ? (b + 1) * blk : M;
+            for (size_t id = b * blk; id < e; ++id) s += prob[id];
+            bsum[b] = s;
+            total += s;
+        }
+        double number = orc_mt_uniform(rng) * total;                  /* :430 */
+        /* upper_bound on the inclusive scan: first slot whose cumulative sum exceeds `number` (:444) */
+        double acc = 0.0;
+        size_t b = 0;
+        while (b + 1 < nb && !(number < acc + bsum[b])) { acc += bsum[b]; ++b; }
+        size_t id = b * blk, e = (b + 1) * blk < M ? (b + 1) * blk : M;
+        double c = acc;
+        for (; id < e; ++id) { c += prob[id]; if (number < c) break; }
+        if (id >= M) id = M - 1;
+        int i = (int)(id / nn), j = neigh_idx[id], et = type[id];
+        if (ev_log) { ev_log[3 * count] = i; ev_log[3 * count + 1] = j; ev_log[3 * count + 2] = et; }
+        /* execute_event :284-331 */
+        if (et == EV_VACANCY_GENERATION) { element[i] = OXYGEN_DEFECT; element[j] = VACANCY; charge[i] = -2; charge[j] = 2; }
+        else if (et == EV_VACANCY_RECOMBINATION) { element[i] = DEFECT; element[j] = O_EL; charge[i] = 0; charge[j] = 0; }
+        else if (et == EV_VACANCY_DIFFUSION || et == EV_ION_DIFFUSION) {
+            int te = element[i]; element[i] = element[j]; element[j] = te;
+            int tc = charge[i]; charge[i] = charge[j]; charge[j] = tc;
+        }
+        /* zero_out_events_split :237-256 */
+        for (size_t s = 0; s < M; ++s) {
+            int ii = (int)(s / nn), jj = neigh_idx[s];
+            if (jj >= 0 && (ii == i || jj == j || ii == j || jj == i)) { type[s] = EV_NULL; prob[s] = 0.0; }
+        }
+        t = -log(orc_mt_uniform(rng)) / total;                        /* :479: the total from before the zero-out */
+        ++count;
+    }
+    *event_time = t;
+    free(type); free(prob); free(bsum);
+    return count;
+}
+
 /* sum_AB_into_A, src/potential_solver_gpu.cu:832-843 */
 void orc_sum_AB_into_A(double *A, const double *B, int N)
 {

@@ -243,6 +243,54 @@ def halo_lists(row_ptr, col, P, rank):
     return out
 
 
+class MT19937(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+def mt_uniform_stream(seed, n):
+    """n draws of std::uniform_real_distribution<double>(0,1) over std::mt19937(seed) (src/random_num.h)."""
+    L = lib()
+    L.orc_mt_uniform.restype = C.c_double
+    g = MT19937()
+    L.orc_mt_seed(C.byref(g), C.c_uint32(seed))
+    return np.array([L.orc_mt_uniform(C.byref(g)) for _ in range(n)])
+
+
+def mt_raw_stream(seed, n):
+    L = lib()
+    L.orc_mt_next.restype = C.c_uint32
+    g = MT19937()
+    L.orc_mt_seed(C.byref(g), C.c_uint32(seed))
+    return np.array([L.orc_mt_next(C.byref(g)) for _ in range(n)], dtype=np.uint64)
+
+
+def kmc_step(xyz, neigh_idx, layer, T_bg, freq, sigma, k, pot, element, charge, layers, rng_state, blk=2048,
+             max_events=4096):
+    """execute_kmc_step_mpi (src/kmc_events.cu:333-563), one rank.  rng_state: an MT19937 (advanced in place).
+    Returns (event_time, n_events, log[n,3], element_after, charge_after)."""
+    L = lib()
+    L.orc_kmc_step.restype = C.c_int
+    N, nn = neigh_idx.shape
+    el = _i(element).copy()
+    ch = _i(charge).copy()
+    t = C.c_double()
+    log = np.zeros(3 * max_events, np.int32)
+    E = [_f([l[key] for l in layers]) for key in ("E_gen_0", "E_rec_1", "E_diff_2", "E_diff_3")]
+    L.orc_kmc_step.argtypes = [C.c_int, C.c_int, _ip, _ip, C.c_double, C.c_double, C.c_double, C.c_double,
+                               _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, C.c_void_p, C.c_int, C.c_int,
+                               C.POINTER(C.c_double), _ip]
+    n = L.orc_kmc_step(N, nn, _i(neigh_idx).reshape(-1), _i(layer), T_bg, freq, sigma, k,
+                       _f(xyz[:, 0]), _f(xyz[:, 1]), _f(xyz[:, 2]), _f(pot), el, ch, E[0], E[1], E[2], E[3],
+                       C.cast(C.byref(rng_state), C.c_void_p), blk, max_events, C.byref(t), log)
+    return t.value, n, log[:3 * n].reshape(-1, 3).copy(), el, ch
+
+
+def mt_state(seed):
+    g = MT19937()
+    lib().orc_mt_seed(C.byref(g), C.c_uint32(seed))
+    return g
+
+
 def update_temperature_global(site_power, T_bg, a, b, number_steps, C_thermal, small_step):
     return lib().orc_update_temperature_global(_f(site_power), len(site_power), T_bg, a, b, number_steps,
                                                C_thermal, small_step)

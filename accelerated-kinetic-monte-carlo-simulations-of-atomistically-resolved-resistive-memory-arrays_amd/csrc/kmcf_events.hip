@@ -3,11 +3,14 @@
 // (:128-207), zero_out_events_split (:237-256), read_out_event (:257-269), execute_event (:284-331).
 //
 // Reference per EVENT: thrust::inclusive_scan over all count*nn slots (16 B/slot read + 8 B/slot written),
-// a device upper_bound, a full zero-out pass.  Here the list keeps one partial sum per 2048-slot block:
-//   per step : build kernel (type u8 + probability f64 per slot) + block sums
-//   per event: total = fixed-order sum of the block sums (1 block) -> host draws -> select kernel walks the
-//              block sums, then the slots of ONE block -> execute -> zero-out pass that also refreshes the
-//              block sums (one read of neigh/prob per event, no scan array at all).
+// a device upper_bound, a full zero-out pass, three host syncs.  Here the list keeps a two-level sum tree
+// (one sum per 2048-slot tile, one per group of 256 tiles), no scan array at all:
+//   per step : build kernel (type u8 + probability f64 per slot), tile sums, symmetry check of the lists
+//   per event: group sums + total (one small kernel) -> select: walk <= G groups, <= 256 tiles, <= 2048
+//              slots -> execute -> zero the events touching the pair and refresh the affected tile sums.
+//              One rank with symmetric neighbour lists: only the rows of i, j and of their listed
+//              neighbours are visited (<= 2 + 2 nn rows, <= 4 nn + 4 tiles) and the whole event needs ONE
+//              host sync; otherwise a full pass over this rank's slots (the reference's way).
 // Same selection rule (first slot whose inclusive cumulative sum exceeds u * total), same event rules,
 // same loop (events are drawn until the LAST drawn residence time reaches 1/freq; that last draw is the
 // returned time).  Ranks own contiguous site ranges; the partial totals are all-gathered and the rank
@@ -40,7 +43,8 @@ namespace {
 
 constexpr int EL_DEFECT = 0, EL_OXYGEN_DEFECT = 1, EL_VACANCY = 2, EL_O = 3;       // src/utils.h:37-44
 constexpr int EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_ODIFF = 3, EV_NULL = 4;     // EVENTTYPE, src/utils.h:53-60
-constexpr int EV_TILE = 2048;                                                       // slots per block sum
+constexpr int EV_TILE = 2048;                                                       // slots per tile sum
+constexpr int EV_GROUP = 256;                                                       // tiles per group sum
 constexpr int MAX_LAYERS = 8;
 
 struct layer_energies { double gen[MAX_LAYERS], rec[MAX_LAYERS], vdiff[MAX_LAYERS], odiff[MAX_LAYERS]; };
@@ -116,13 +120,13 @@ __global__ __launch_bounds__(KMCF_BLOCK) void build_event_list_kernel(
     }
 }
 
-// Zero the events touching the executed pair (zero_out_events_split, :237-256) and refresh the block sum.
-// i_del < 0: plain block sums (first call of a step).
+// Full pass: zero the events touching the executed pair (zero_out_events_split, :237-256) and refresh every
+// tile sum.  i_del < 0: plain tile sums (first call of a step).
 __global__ __launch_bounds__(KMCF_BLOCK) void zero_and_sum_kernel(size_t M, int start_i, int nn,
                                                                   const int *__restrict__ neigh_idx,
                                                                   unsigned char *__restrict__ event_type,
                                                                   double *__restrict__ event_prob, int i_del, int j_del,
-                                                                  double *__restrict__ bsum)
+                                                                  double *__restrict__ tsum)
 {
     __shared__ double lds4[4];
     const size_t base = (size_t)blockIdx.x * EV_TILE;
@@ -142,29 +146,98 @@ __global__ __launch_bounds__(KMCF_BLOCK) void zero_and_sum_kernel(size_t M, int 
         s += p;
     }
     const double tot = block_sum_ev(s, lds4);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+    if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
 }
 
-// total = sum of the block sums, fixed order
-__global__ __launch_bounds__(KMCF_BLOCK) void total_kernel(int nb, const double *__restrict__ bsum, double *__restrict__ total)
+// Neighbour-list shortcut of the zero-out (one rank, symmetric lists): rows i_del and j_del lose all their
+// events; a row n that lists i_del or j_del is, by symmetry, listed by them.  One block; the affected
+// tile ids go to aff[0 .. 4 nn + 4) (-1 = none; duplicates are harmless).
+__global__ void zero_rows_kernel(int nn, const int *__restrict__ neigh_idx, unsigned char *__restrict__ event_type,
+                                 double *__restrict__ event_prob, const int *__restrict__ ijevent, int *__restrict__ aff)
+{
+    const int i_del = ijevent[0], j_del = ijevent[1];
+    for (int t = threadIdx.x; t < 2 * nn; t += blockDim.x) {
+        const int s = t < nn ? i_del : j_del;
+        const size_t own = (size_t)s * nn + (t % nn);
+        if (neigh_idx[own] >= 0) { event_type[own] = (unsigned char)EV_NULL; event_prob[own] = 0.0; }
+        const int n = neigh_idx[own];
+        aff[2 * t] = aff[2 * t + 1] = -1;
+        if (n >= 0) {
+            const size_t rb = (size_t)n * nn;
+            for (int q = 0; q < nn; ++q) {
+                const int jj = neigh_idx[rb + q];
+                if (jj == i_del || jj == j_del) { event_type[rb + q] = (unsigned char)EV_NULL; event_prob[rb + q] = 0.0; }
+            }
+            aff[2 * t] = (int)(rb / EV_TILE);
+            aff[2 * t + 1] = (int)((rb + nn - 1) / EV_TILE);
+        }
+    }
+    if (threadIdx.x < 2) {
+        const size_t rb = (size_t)(threadIdx.x == 0 ? i_del : j_del) * nn;
+        aff[4 * nn + 2 * threadIdx.x] = (int)(rb / EV_TILE);
+        aff[4 * nn + 2 * threadIdx.x + 1] = (int)((rb + nn - 1) / EV_TILE);
+    }
+}
+
+// refresh the tile sums listed in aff (one block per entry)
+__global__ __launch_bounds__(KMCF_BLOCK) void tile_sum_kernel(size_t M, const double *__restrict__ event_prob,
+                                                              const int *__restrict__ aff, double *__restrict__ tsum)
 {
     __shared__ double lds4[4];
+    const int tile = aff[blockIdx.x];
+    if (tile < 0) return;
+    const size_t base = (size_t)tile * EV_TILE;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += KMCF_BLOCK) s += bsum[b];
-    const double t = block_sum_ev(s, lds4);
-    if (threadIdx.x == 0) *total = t;
+    for (int t = threadIdx.x; t < EV_TILE; t += KMCF_BLOCK) {
+        const size_t id = base + t;
+        if (id >= M) break;
+        s += event_prob[id];
+    }
+    const double tot = block_sum_ev(s, lds4);
+    if (threadIdx.x == 0) tsum[tile] = tot;
 }
 
-// First slot whose inclusive cumulative sum exceeds `number` (thrust::upper_bound on the scan, :444).
-// One wave: sequential walk over the block sums, then over the slots of the block that holds the number.
-__global__ void select_event_kernel(size_t M, int nb, int start_i, int nn, double number, const double *__restrict__ bsum,
-                                    const double *__restrict__ event_prob, const unsigned char *__restrict__ event_type,
-                                    const int *__restrict__ neigh_idx, int *__restrict__ ijevent)
+// group sums (sequential over the <= 256 tiles of a group, one thread per group) and, by thread 0 of the
+// last block to finish ... kept simple: a second 1-thread kernel adds the groups up.
+__global__ __launch_bounds__(KMCF_BLOCK) void group_sum_kernel(int nb, const double *__restrict__ tsum, int ng, double *__restrict__ gsum)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const int b0 = g * EV_GROUP, b1 = min(b0 + EV_GROUP, nb);
+    double s = 0.0;
+    for (int b = b0; b < b1; ++b) s += tsum[b];
+    gsum[g] = s;
+}
+
+__global__ void total_kernel(int ng, const double *__restrict__ gsum, double *__restrict__ total)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int g = 0; g < ng; ++g) s += gsum[g];
+    *total = s;
+}
+
+// First slot whose inclusive cumulative sum exceeds the drawn number (thrust::upper_bound on the scan,
+// :444): walk the groups, then the tiles of one group, then the slots of one tile.  number < 0: the
+// number is u * total with u given (single-rank path: one host sync per event); out[3..4] = total bits.
+__global__ void select_event_kernel(size_t M, int nb, int ng, int start_i, int nn, double number, double u,
+                                    const double *__restrict__ gsum, const double *__restrict__ tsum,
+                                    const double *__restrict__ event_prob, const unsigned char *__restrict__ event_type,
+                                    const int *__restrict__ neigh_idx, int *__restrict__ ijevent, double *__restrict__ total_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (number < 0) {
+        double total = 0.0;
+        for (int g = 0; g < ng; ++g) total += gsum[g];
+        *total_out = total;
+        number = u * total;
+    }
     double acc = 0.0;
-    int b = 0;
-    while (b + 1 < nb && !(number < acc + bsum[b])) { acc += bsum[b]; ++b; }
+    int g = 0;
+    while (g + 1 < ng && !(number < acc + gsum[g])) { acc += gsum[g]; ++g; }
+    int b = g * EV_GROUP;
+    const int b_end = min(b + EV_GROUP, nb);
+    while (b + 1 < b_end && !(number < acc + tsum[b])) { acc += tsum[b]; ++b; }
     size_t id = (size_t)b * EV_TILE;
     const size_t e = id + EV_TILE < M ? id + EV_TILE : M;
     double c = acc;
@@ -185,6 +258,20 @@ __global__ void execute_event_kernel(int *__restrict__ site_element, int *__rest
     else if (et == EV_VDIFF || et == EV_ODIFF) {
         const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
         const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+    }
+}
+
+// every listed neighbour j of i lists i back?  (one rank holds all rows)
+__global__ __launch_bounds__(KMCF_BLOCK) void check_symmetry_kernel(int N, int nn, const int *__restrict__ neigh_idx, int *__restrict__ asym)
+{
+    const size_t M = (size_t)N * nn;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < M; id += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(id / nn), j = neigh_idx[id];
+        if (j < 0) continue;
+        if (j >= N) { *asym = 1; continue; }
+        bool found = false;
+        for (int q = 0; q < nn; ++q) found |= (neigh_idx[(size_t)j * nn + q] == i);
+        if (!found) *asym = 1;
     }
 }
 
@@ -210,69 +297,103 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
     const int count = h_count[rank], start_i = h_displs[rank];
     const size_t M = (size_t)count * nn;
     const int nb = (int)((M + EV_TILE - 1) / EV_TILE);
+    const int ng = std::max((nb + EV_GROUP - 1) / EV_GROUP, 1);
     layer_energies E;
     for (int l = 0; l < MAX_LAYERS; ++l) {
         E.gen[l] = l < num_layers ? h_E_gen[l] : 0.0; E.rec[l] = l < num_layers ? h_E_rec[l] : 0.0;
         E.vdiff[l] = l < num_layers ? h_E_Vdiff[l] : 0.0; E.odiff[l] = l < num_layers ? h_E_Odiff[l] : 0.0;
     }
     unsigned char *d_type = nullptr;
-    double *d_prob = nullptr, *d_bsum = nullptr, *d_tot = nullptr;
-    int *d_ij = nullptr;
+    double *d_prob = nullptr, *d_tsum = nullptr, *d_gsum = nullptr, *d_tot = nullptr;
+    int *d_ij = nullptr, *d_aff = nullptr, *d_asym = nullptr;
+    const int n_aff = 4 * nn + 4;
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_type), std::max<size_t>(M, 1)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_prob), std::max<size_t>(M, 1) * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_bsum), (size_t)std::max(nb, 1) * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_tsum), (size_t)std::max(nb, 1) * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_gsum), (size_t)ng * sizeof(double)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_tot), (size_t)P * sizeof(double)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_ij), (size_t)3 * P * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_aff), (size_t)n_aff * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_asym), sizeof(int)));
+    KMCF_HIP(hipMemsetAsync(d_gsum, 0, (size_t)ng * sizeof(double), st));
+    KMCF_HIP(hipMemsetAsync(d_asym, 0, sizeof(int), st));
     std::vector<int> ones(P, 1), iota(P), threes(P, 3), iota3(P);
     for (int q = 0; q < P; ++q) { iota[q] = q; iota3[q] = 3 * q; }
     int rc = KMCF_OK;
     auto fail = [&](int code) { rc = code; };
+    bool fast = false;   // neighbour-list zero-out + one host sync per event
     if (M > 0) {
         int64_t g = ((int64_t)M + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
         if (g > 16384) g = 16384;
         build_event_list_kernel<<<(int)g, KMCF_BLOCK, 0, st>>>(N, count, start_i, nn, d_neigh_idx, d_site_layer, T_bg, freq, sigma, k,
                                                                d_x, d_y, d_z, d_site_potential_charge, d_site_element,
                                                                d_site_charge, E, d_type, d_prob);
-        zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, -1, -1, d_bsum);
+        zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, -1, -1, d_tsum);
+        if (P == 1 && count == N && !getenv("KMCF_EVENTS_FULLSCAN")) {
+            check_symmetry_kernel<<<(int)g, KMCF_BLOCK, 0, st>>>(N, nn, d_neigh_idx, d_asym);
+            int asym = 1;
+            if (hipMemcpyAsync(&asym, d_asym, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) fail(KMCF_ERR_HIP);
+            fast = (asym == 0);
+        }
     }
     double t = 0.0;
     int nev = 0;
     std::vector<double> totals(P);
+    const int ggrid = (ng + KMCF_BLOCK - 1) / KMCF_BLOCK;
     while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                          // :418
-        if (M > 0) total_kernel<<<1, KMCF_BLOCK, 0, st>>>(nb, d_bsum, d_tot + rank);
-        else if (hipMemsetAsync(d_tot + rank, 0, sizeof(double), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
-        if (kmcf_comm_allgatherv_double(c, d_tot, ones.data(), iota.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }   // MPI_Allgather :423
-        if (hipMemcpyAsync(totals.data(), d_tot, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
-        for (int q = 1; q < P; ++q) totals[q] += totals[q - 1];                           // :425-427
-        const double total = totals[P - 1];
-        double number = next_random(rng_user) * total;                                    // :430
-        int source_rank = P - 1;
-        for (int q = 0; q < P; ++q)
-            if (number < totals[q]) { source_rank = q; break; }                           // :432-437
-        if (hipMemsetAsync(d_ij + 3 * rank, 0xff, 3 * sizeof(int), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
-        if (rank == source_rank && M > 0) {
-            if (rank > 0) number -= totals[rank - 1];                                     // :440-442
-            select_event_kernel<<<1, 64, 0, st>>>(M, nb, start_i, nn, number, d_bsum, d_prob, d_type, d_neigh_idx, d_ij + 3 * rank);
-        }
-        if (kmcf_comm_allgatherv_int(c, d_ij, threes.data(), iota3.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }     // MPI_Bcast :455-459
+        if (M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
+        double total = 0.0;
         int ij[3];
-        if (hipMemcpyAsync(ij, d_ij + 3 * source_rank, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        int source_rank = 0;
+        if (fast) {
+            const double u = next_random(rng_user);                                       // :430
+            select_event_kernel<<<1, 64, 0, st>>>(M, nb, ng, start_i, nn, -1.0, u, d_gsum, d_tsum, d_prob, d_type, d_neigh_idx,
+                                                  d_ij, d_tot);
+            execute_event_kernel<<<1, 64, 0, st>>>(d_site_element, d_site_charge, d_ij);
+            zero_rows_kernel<<<1, 128, 0, st>>>(nn, d_neigh_idx, d_type, d_prob, d_ij, d_aff);
+            tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
+            if (hipMemcpyAsync(ij, d_ij, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&total, d_tot, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+        } else {
+            total_kernel<<<1, 64, 0, st>>>(ng, d_gsum, d_tot + rank);
+            if (kmcf_comm_allgatherv_double(c, d_tot, ones.data(), iota.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }   // MPI_Allgather :423
+            if (hipMemcpyAsync(totals.data(), d_tot, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            for (int q = 1; q < P; ++q) totals[q] += totals[q - 1];                       // :425-427
+            total = totals[P - 1];
+            double number = next_random(rng_user) * total;                                // :430
+            source_rank = P - 1;
+            for (int q = 0; q < P; ++q)
+                if (number < totals[q]) { source_rank = q; break; }                       // :432-437
+            if (hipMemsetAsync(d_ij + 3 * rank, 0xff, 3 * sizeof(int), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            if (rank == source_rank && M > 0) {
+                if (rank > 0) number -= totals[rank - 1];                                 // :440-442
+                if (number < 0) number = 0;
+                select_event_kernel<<<1, 64, 0, st>>>(M, nb, ng, start_i, nn, number, 0.0, d_gsum, d_tsum, d_prob, d_type,
+                                                      d_neigh_idx, d_ij + 3 * rank, d_tot + rank);
+            }
+            if (kmcf_comm_allgatherv_int(c, d_ij, threes.data(), iota3.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }  // MPI_Bcast :455-459
+            if (hipMemcpyAsync(ij, d_ij + 3 * source_rank, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            if (ij[0] >= 0 && ij[0] < N && ij[1] >= 0 && ij[1] < N) {
+                execute_event_kernel<<<1, 64, 0, st>>>(d_site_element, d_site_charge, d_ij + 3 * source_rank);
+                if (M > 0) zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, ij[0], ij[1], d_tsum);
+            }
+        }
         if (ij[0] < 0 || ij[0] >= N || ij[1] < 0 || ij[1] >= N) {
             kmcf_set_error("kmcf_execute_kmc_step: no event could be selected (total rate %g)", total);
             fail(KMCF_ERR_STATE);
             break;
         }
-        execute_event_kernel<<<1, 64, 0, st>>>(d_site_element, d_site_charge, d_ij + 3 * source_rank);
-        if (M > 0) zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, ij[0], ij[1], d_bsum);
         if (h_event_log) { h_event_log[3 * nev] = ij[0]; h_event_log[3 * nev + 1] = ij[1]; h_event_log[3 * nev + 2] = ij[2]; }
         t = -std::log(next_random(rng_user)) / total;                                     // :479
         ++nev;
     }
     if (rc == KMCF_OK && hipStreamSynchronize(st) != hipSuccess) rc = KMCF_ERR_HIP;
     if (rc == KMCF_ERR_HIP) kmcf_set_error("kmcf_execute_kmc_step: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-    hipFree(d_type); hipFree(d_prob); hipFree(d_bsum); hipFree(d_tot); hipFree(d_ij);
+    hipFree(d_type); hipFree(d_prob); hipFree(d_tsum); hipFree(d_gsum); hipFree(d_tot); hipFree(d_ij); hipFree(d_aff); hipFree(d_asym);
     *event_time = t;
     if (n_events) *n_events = nev;
     return rc;

@@ -98,7 +98,8 @@ def load_device_5nm(state="init"):
                 Vd=float(g["Vd"]), nn_dist=float(g["nn_dist"]), pbc=int(g["pbc"]), sigma=float(g["sigma"]),
                 k=8.987552e9 / float(g["epsilon"]), high_G=1.0, low_G=1e-8,   # src/input_parser.cpp:391-394
                 potential_snap6=g["potential_snap6"].copy(), element_snap6=g["element_snap6"].astype(np.int32),
-                name="5nm_device")
+                kmc_times=g["kmc_times"].copy(), t_switch=float(g["t_switch"]), freq=float(g["attempt_frequency"]),
+                T_bg=float(g["background_temp"]), name="5nm_device")
 
 
 def _stripes(coord, length, n_lines, fill):

@@ -11,11 +11,14 @@
  * every function here restates the reference's *GPU* arithmetic, op for op, and
  * cites the file:line it follows (paths relative to the reference checkout).
  *
- * Pinning: parity is pinned by the reference's only shipped golden output,
- * structures/5nm_device/expected_output/Results_5.000000/snapshot_6.xyz
- * (tests/test_oracle_golden.py, loose end-to-end pin) plus derived vectors
- * under tests/golden/.  At kernel granularity the reference holds no
- * known-answer vectors, so per-kernel parity is "pinned by this restatement".
+ * Pinning: the reference ships one golden run, structures/5nm_device/expected_output/
+ * (output1_0.txt + Results_5.000000/snapshot_{init,6}.xyz).  Chained in the order of
+ * src/kmc_main.cpp:328-500, the functions below reproduce it end to end
+ * (tests/test_oracle_golden.py::test_oracle_reproduces_reference_trajectory): the six
+ * cumulative "KMC time" values to < 2e-3, the loop exit after six steps, the element of
+ * every site of snapshot_6.xyz (the same eight events selected with std::mt19937(1)) and
+ * its potential column.  Derived vectors live under tests/golden/.  At kernel granularity
+ * the reference holds no known-answer vectors; those are pinned by this restatement.
  */
 #include <math.h>
 #include <stdint.h>
@@ -839,19 +842,30 @@ int orc_kmc_step(int N, int nn, const int *neigh_idx, const int *layer, double T
     double t = 0.0;
     int count = 0;
     while (t < 1 / freq && count < max_events) {
+        /* two-level sums like the library: tiles of `blk` slots, groups of 256 tiles */
+        const size_t grp = 256, ng = (nb + grp - 1) / grp;
         double total = 0.0;
         for (size_t b = 0; b < nb; ++b) {
             double s = 0.0;
             size_t e = (b + 1) * blk < M ? (b + 1) * blk : M;
             for (size_t id = b * blk; id < e; ++id) s += prob[id];
             bsum[b] = s;
+        }
+        double gsum[4096];
+        for (size_t g = 0; g < ng; ++g) {
+            double s = 0.0;
+            size_t b1 = (g + 1) * grp < nb ? (g + 1) * grp : nb;
+            for (size_t b = g * grp; b < b1; ++b) s += bsum[b];
+            gsum[g] = s;
             total += s;
         }
         double number = orc_mt_uniform(rng) * total;                  /* :430 */
         /* upper_bound on the inclusive scan: first slot whose cumulative sum exceeds `number` (:444) */
         double acc = 0.0;
-        size_t b = 0;
-        while (b + 1 < nb && !(number < acc + bsum[b])) { acc += bsum[b]; ++b; }
+        size_t g = 0;
+        while (g + 1 < ng && !(number < acc + gsum[g])) { acc += gsum[g]; ++g; }
+        size_t b = g * grp, b_end = (g + 1) * grp < nb ? (g + 1) * grp : nb;
+        while (b + 1 < b_end && !(number < acc + bsum[b])) { acc += bsum[b]; ++b; }
         size_t id = b * blk, e = (b + 1) * blk < M ? (b + 1) * blk : M;
         double c = acc;
         for (; id < e; ++id) { c += prob[id]; if (number < c) break; }

@@ -43,6 +43,13 @@ def main():
     res = os.path.join(S5, "expected_output", "Results_5.000000")
     el_init, cols_init = read_xyz(os.path.join(res, "snapshot_init.xyz"), 5)
     el_s6, cols_s6 = read_xyz(os.path.join(res, "snapshot_6.xyz"), 5)
+    # expected_output/output1_0.txt: "KMC time is: ..." after each of the 6 KMC steps of the 5 V bias point
+    kmc_times = []
+    with open(os.path.join(S5, "expected_output", "output1_0.txt")) as f:
+        for line in f:
+            if line.startswith("KMC time is:"):
+                kmc_times.append(float(line.split(":")[1]))
+    assert len(kmc_times) == 6, kmc_times
     assert np.abs(cols_init[:, :3] - xyz).max() < 1e-4
     assert np.abs(cols_s6[:, :3] - xyz).max() < 1e-4
     np.savez_compressed(
@@ -54,6 +61,10 @@ def main():
         potential_snap6=cols_s6[:, 3],  # site_potential_charge after sum_and_gather, 6 sig. digits
         power_snap6=cols_s6[:, 4],
         potential_init=cols_init[:, 3],
+        kmc_times=np.asarray(kmc_times),   # cumulative KMC time after steps 1..6 (t_switch = 1e-12 s ends the loop)
+        t_switch=np.float64(1e-12),
+        attempt_frequency=np.float64(10e13),
+        background_temp=np.float64(300.0),
         # structures/5nm_device/parameters.txt
         lattice=np.array([108.984220, 51.150000, 51.150000]),
         Vd=np.float64(5.0),

@@ -124,6 +124,41 @@ def test_reference_snapshot_pin(oracle, dev5, ref5):
     assert np.all(d["potential_snap6"][:NL] == 0)
 
 
+def test_oracle_reproduces_reference_trajectory(oracle, km, dev5, ref5):
+    """The strong pin of the oracle: the whole per-step loop of src/kmc_main.cpp:328-500 restated on the CPU
+    (charges, K assembly, PCG, pairwise term, event step with std::mt19937(1)) reproduces the reference's
+    expected_output: the six "KMC time is:" lines (< 2e-3 relative), the exit after six steps, and the element
+    of every site of snapshot_6.xyz (the same eight events)."""
+    d = dev5
+    N, NL = d["N"], d["N_contact"]
+    ks, nl = ref5["ks"], ref5["neigh"]
+    layers = km.structure.LAYERS
+    lay = km.solvers.site_layers(d["xyz"][:, 0], layers)
+    el = d["element"].copy()
+    ch = np.zeros(N, np.int32)
+    xb = np.zeros(ks.n)
+    g = oracle.mt_state(km.structure.RND_SEED_KMC)
+    kmc_time, times, nev = 0.0, [], 0
+    while kmc_time < d["t_switch"] and len(times) < 12:
+        ch = oracle.update_charge(el, ch, nl, d["metals"])
+        A = oracle.assemble_K(ks, el, ch, d["metals"], d["high_G"], d["low_G"], d["Vd"])
+        xb, it, rel = oracle.pcg_jacobi(ks.row_ptr, ks.col, A["val"], A["rhs"], xb, A["dinv"], 1e-14 * ks.n, 10000)
+        pot = oracle.poisson_gridless(d["xyz"], ch, d["sigma"], d["k"])
+        pot[NL:NL + ks.n] += xb
+        t, n, log, el, ch = oracle.kmc_step(d["xyz"], nl, lay, d["T_bg"], d["freq"], d["sigma"], d["k"], pot, el, ch,
+                                            layers, g, max_events=1000)
+        kmc_time += t
+        times.append(kmc_time)
+        nev += n
+    assert len(times) == 6
+    np.testing.assert_allclose(times, d["kmc_times"], rtol=2e-3)
+    assert nev == 8
+    assert np.array_equal(el, d["element_snap6"])
+    idx = np.arange(NL, N - NL)
+    err = np.abs(pot[idx] - d["potential_snap6"][idx])
+    assert np.median(err) <= 1e-5
+
+
 def test_partition_rule(oracle):
     c, dsp = oracle.partition(36498, 8)
     assert c.tolist() == [4563, 4563, 4562, 4562, 4562, 4562, 4562, 4562] and dsp[-1] + c[-1] == 36498

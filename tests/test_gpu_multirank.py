@@ -48,9 +48,26 @@ def _run_ranks(km, d, P, ref_charge):
             st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                                    d["nn_dist"], len(d["metals"]), 0)
             S.sum_and_gather_potential(buf, NL, comm)
-            out[r] = dict(st=st, info=info, charge=charge, Ap=Ap.cpu().numpy(), r0=r0, nr=nr,
-                          v=buf.site_potential_boundary.cpu().numpy().copy(),
-                          tot=buf.site_potential_charge.cpu().numpy().copy())
+            res = dict(st=st, info=info, charge=charge, Ap=Ap.cpu().numpy(), r0=r0, nr=nr,
+                       v=buf.site_potential_boundary.cpu().numpy().copy(),
+                       tot=buf.site_potential_charge.cpu().numpy().copy())
+            # second pass like a KMC step of main: pairwise rows of this rank + gather + sum, then the event step
+            # with the partial totals all-gathered and the owning rank selecting (kmc_events.cu:423-470)
+            S.compute_cutoff_list(comm, buf, 20.0)
+            buf.site_potential_charge.zero_()
+            S.poisson_gridless_gpu(buf, comm)
+            S.sum_and_gather_potential(buf, NL, comm)
+            res["tot2"] = buf.site_potential_charge.cpu().numpy().copy()
+            lay = torch.as_tensor(S.site_layers(d["xyz"][:, 0], km.structure.LAYERS), device="cuda")
+            rng = S.RandomNumberGenerator(1)
+            t, nev, log = S.execute_kmc_step_mpi(comm, d["N"], comm.counts_events, comm.displs_events, 52, buf.neigh_idx,
+                                                 lay, 150.0, d["freq"], d["sigma"], d["k"], buf.site_x, buf.site_y,
+                                                 buf.site_z, buf.site_potential_charge, buf.site_element,
+                                                 buf.site_charge, rng, km.structure.LAYERS, max_events=2000,
+                                                 return_log=True)
+            res.update(ev_t=t, ev_n=nev, ev_log=log, el_after=buf.site_element.cpu().numpy().copy(),
+                       ch_after=buf.site_charge.cpu().numpy().copy())
+            out[r] = res
             buf.freeGPUmemory()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -109,3 +126,18 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
     # all ranks hold bit-identical replicated solutions
     for o in out[1:]:
         assert np.array_equal(o["v"], out[0]["v"])
+    # pairwise term computed row-block-wise and gathered == the oracle's, on every rank
+    pw = oracle.poisson_gridless(d["xyz"], ref5["charge"], d["sigma"], d["k"], 20.0)
+    for o in out:
+        assert np.abs((o["tot2"] - o["v"]) - pw).max() <= 1e-12 * np.abs(pw).max()
+        assert np.array_equal(o["tot2"], out[0]["tot2"])
+    # event step across ranks: same events as the oracle's single-list selection fed with the same potentials
+    lay = km.solvers.site_layers(d["xyz"][:, 0], km.structure.LAYERS)
+    g = oracle.mt_state(1)
+    t_o, n_o, log_o, el_o, ch_o = oracle.kmc_step(d["xyz"], ref5["neigh"], lay, 150.0, d["freq"], d["sigma"], d["k"],
+                                                  out[0]["tot2"], d["element"], ref5["charge"], km.structure.LAYERS, g,
+                                                  max_events=2000)
+    for o in out:
+        assert o["ev_n"] == n_o and np.array_equal(o["ev_log"], log_o)
+        assert o["ev_t"] == pytest.approx(t_o, rel=1e-12)
+        assert np.array_equal(o["el_after"], el_o) and np.array_equal(o["ch_after"], ch_o)

@@ -144,7 +144,13 @@ struct kmcf_matrix {
     int spmv_grid = 0;                 // interior pass grid (= number of pAp partials it writes)
     int spmv_grid_b = 0;               // boundary pass grid
     int spmv_lpr = 16;                 // lanes per row (vec kernel)
-    int spmv_kind = 0;                 // 0: vec<LPR>, 1: stream (nnz-chunked, LDS row reduction)
+    int spmv_kind = 0;                 // 0: vec<LPR>, 1: stream (nnz-chunked, LDS row reduction), 2: window
+    // window kernel (kind 2): tiles of whole rows whose distinct columns (<= spmv_wmax) are staged in LDS
+    int n_tiles = 0;
+    int spmv_wmax = 0;
+    int2 *d_tile = nullptr;            // (first row, first window slot) per tile, n_tiles + 1
+    int *d_wcol = nullptr;             // column of each window slot (ascending inside a tile)
+    unsigned short *d_idx16 = nullptr; // per nnz: window slot of its column inside the tile
     int spmv_u = 8;                    // stream: nnz per thread per chunk
     int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction
     int n_chunks = 0;

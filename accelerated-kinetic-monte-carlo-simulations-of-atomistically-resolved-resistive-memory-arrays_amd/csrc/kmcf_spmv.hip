@@ -21,6 +21,8 @@
 // by the consumer kernel) and map blocks to rows XCD-aware: blocks with equal
 // blockIdx % 8 (same XCD, same L2) walk one contiguous eighth of the matrix, so each L2
 // holds one window of x.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "kmcf_internal.hpp"
@@ -93,6 +95,86 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
         const int lane = tid % LPR2;
         const int nrows = r1 - r0;
         const int passes = (nrows + RPP - 1) / RPP;
+        for (int ps = 0; ps < passes; ++ps) {
+            const int rr = r0 + ps * RPP + tid / LPR2;
+            const bool valid = rr < r1;
+            double s = 0.0;
+            if (valid) {
+                const int b = row_ptr[rr] - base, e = row_ptr[rr + 1] - base;
+                for (int j = b + lane; j < e; j += LPR2) s += prod[j];
+            }
+            if (LPR2 > 1) s = wave_sum_width(s, LPR2);
+            if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
+                y[rr] = s;
+                if (DOT) dot += x[rr] * s;
+            }
+        }
+        __syncthreads();
+    }
+    if (DOT) {
+        double t = block_sum_256(dot, lds4);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ window kernel
+// Tiles of whole rows (<= 256*U nnz) whose distinct columns (<= 256*WQ of them, found at plan time) are
+// staged once in LDS: the tile's window map is read coalesced, x is fetched run by run (neighbouring lanes
+// read neighbouring addresses, so the texture path merges them), and the per-entry gather happens in LDS
+// through 16-bit window slots instead of one L1 tag lookup per lane (PMC: 45.6 M TCP accesses per launch
+// for the stream kernel, most of them single-lane gathers).  Values keep their CSR order and stay f64.
+template <int U, int WQ, int LPR2, bool DOT, bool SKIP_BOUNDARY>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
+    int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
+    const unsigned short *__restrict__ idx16, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const unsigned char *__restrict__ is_boundary, double *__restrict__ part,
+    const kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double xw[KMCF_BLOCK * WQ];
+    __shared__ double prod[KMCF_BLOCK * U];
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Cx = (n_tiles + 7) >> 3;  // tiles per XCD
+    double dot = 0.0;
+    for (int g = bi; g < Cx; g += nb8) {
+        const int c = xcd * Cx + g;
+        if (c >= n_tiles) break;                       // block-uniform
+        const int2 t0 = tile[c], t1 = tile[c + 1];
+        const int r0 = t0.x, r1 = t1.x, w0 = t0.y, W = t1.y - w0;
+        const int base = row_ptr[r0];
+        const int cnt = row_ptr[r1] - base;
+        // every global load of the tile is issued before the first wait: window map (its dependent x
+        // fetch is the longest chain), then the value / slot streams
+        int wc[WQ];
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int w = q * KMCF_BLOCK + tid;
+            wc[q] = w < W ? __builtin_nontemporal_load(wcol + w0 + w) : -1;
+        }
+        double v[U];
+        unsigned short ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * KMCF_BLOCK + tid;
+            const bool in = i < cnt;
+            v[u] = in ? __builtin_nontemporal_load(val + base + i) : 0.0;
+            ci[u] = in ? __builtin_nontemporal_load(idx16 + base + i) : (unsigned short)0;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wc[q] >= 0) xw[q * KMCF_BLOCK + tid] = x[wc[q]];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * KMCF_BLOCK + tid;
+            if (i < cnt) prod[i] = v[u] * xw[ci[u]];
+        }
+        __syncthreads();
+        constexpr int RPP = KMCF_BLOCK / LPR2;  // rows per pass
+        const int lane = tid % LPR2;
+        const int passes = (r1 - r0 + RPP - 1) / RPP;
         for (int ps = 0; ps < passes; ++ps) {
             const int rr = r0 + ps * RPP + tid / LPR2;
             const bool valid = rr < r1;
@@ -258,9 +340,66 @@ void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     }
 }
 
+#define KMCF_WINDOW_ARGS(isb, part) \
+    m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_val, m->d_p, m->d_Ap, isb, part, m->d_S, chk
+
+template <int U, int WQ>
+void launch_window(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+{
+    hipStream_t st = m->comm->stream;
+    const int chk = skip_if_done ? 1 : 0;
+    int grid = m->spmv_grid;
+    if (!with_dot && getenv("KMCF_SPMV_GRIDX")) grid = (std::min(atoi(getenv("KMCF_SPMV_GRIDX")), m->n_tiles) + 7) / 8 * 8;  // lab
+    const bool skipb = (m->n_halo > 0);
+    if (with_dot) {
+        if (skipb) spmv_window_kernel<U, WQ, 4, true, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(m->d_is_boundary, m->d_part_a));
+        else spmv_window_kernel<U, WQ, 4, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(nullptr, m->d_part_a));
+    } else {
+        if (skipb) spmv_window_kernel<U, WQ, 4, false, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(m->d_is_boundary, nullptr));
+        else spmv_window_kernel<U, WQ, 4, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(nullptr, nullptr));
+    }
+}
+
+// The window kernel walks its tiles in a static loop, so its grid must be exactly what the chip holds at
+// once: with more blocks than resident slots the surplus ones start only after a first-wave block has
+// finished its whole loop (measured 116 us at 2048 blocks vs 102 us at 7 blocks x 256 CUs).
+template <int U, int WQ>
+int window_resident_blocks(bool skipb, int device)
+{
+    int per_cu = 0, cus = 0;
+    hipError_t e = skipb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spmv_window_kernel<U, WQ, 4, true, true>, KMCF_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spmv_window_kernel<U, WQ, 4, true, false>, KMCF_BLOCK, 0);
+    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
+int window_grid(kmcf_matrix *m)
+{
+    const bool skipb = (m->n_halo > 0);
+    const int dev = m->comm->device;
+    int resident = 0;
+    switch (m->spmv_u * 100 + m->spmv_wmax / KMCF_BLOCK) {
+        case 402: resident = window_resident_blocks<4, 2>(skipb, dev); break;
+        case 802: resident = window_resident_blocks<8, 2>(skipb, dev); break;
+        case 804: resident = window_resident_blocks<8, 4>(skipb, dev); break;
+        default: resident = window_resident_blocks<8, 3>(skipb, dev); break;
+    }
+    int g = grid_for(m->n_tiles, 1);
+    if (resident >= 8 && g > resident) g = resident / 8 * 8;
+    return g;
+}
+
 void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
-    if (m->spmv_kind == 1) {
+    if (m->spmv_kind == 2) {
+        const int key = m->spmv_u * 100 + m->spmv_wmax / KMCF_BLOCK;
+        switch (key) {
+            case 402: launch_window<4, 2>(m, with_dot, skip_if_done); break;
+            case 802: launch_window<8, 2>(m, with_dot, skip_if_done); break;
+            case 804: launch_window<8, 4>(m, with_dot, skip_if_done); break;
+            default: launch_window<8, 3>(m, with_dot, skip_if_done); break;
+        }
+    } else if (m->spmv_kind == 1) {
         const int key = m->spmv_u * 100 + m->spmv_lpr2;
         switch (key) {
             case 401: launch_stream<4, 1>(m, with_dot, skip_if_done); break;
@@ -279,6 +418,65 @@ int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+
+// Cuts the rows into tiles for the window kernel: whole rows, at most 256*u entries and 256*wq distinct
+// columns per tile (compact-halo column ids, so halo slots are window columns like any other).  *ok stays
+// false (nothing allocated) if a row does not fit a tile or, with `judge`, if the tiles come out less than
+// half full: columns too scattered for a window, the stream kernel's direct gathers serve those better.
+int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
+{
+    *ok = false;
+    const int n = m->n_loc;
+    if (n == 0 || m->nnz == 0) return KMCF_OK;
+    const std::vector<int> &rp = m->h_row_ptr;
+    const int cap = KMCF_BLOCK * u, wmax = KMCF_BLOCK * wq;
+    std::vector<int> col((size_t)m->nnz);
+    KMCF_HIP(hipMemcpy(col.data(), m->d_col, col.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1);
+    std::vector<int2> tiles;
+    std::vector<int> wcol, uniq;
+    std::vector<unsigned short> idx((size_t)m->nnz);
+    int r = 0;
+    while (r < n) {
+        uniq.clear();
+        int e = r;
+        while (e < n && rp[e + 1] - rp[r] <= cap) {
+            const size_t before = uniq.size();
+            for (int j = rp[e]; j < rp[e + 1]; ++j)
+                if (slot[col[j]] < 0) { slot[col[j]] = 0; uniq.push_back(col[j]); }
+            if ((int)uniq.size() > wmax) {
+                for (size_t q = before; q < uniq.size(); ++q) slot[uniq[q]] = -1;
+                uniq.resize(before);
+                break;
+            }
+            ++e;
+        }
+        if (e == r) return KMCF_OK;              // one row alone exceeds a tile
+        std::sort(uniq.begin(), uniq.end());
+        for (size_t q = 0; q < uniq.size(); ++q) slot[uniq[q]] = (int)q;
+        for (int j = rp[r]; j < rp[e]; ++j) idx[j] = (unsigned short)slot[col[j]];
+        for (int cj : uniq) slot[cj] = -1;
+        tiles.push_back(make_int2(r, (int)wcol.size()));
+        wcol.insert(wcol.end(), uniq.begin(), uniq.end());
+        r = e;
+    }
+    tiles.push_back(make_int2(n, (int)wcol.size()));
+    const int nt = (int)tiles.size() - 1;
+    if (judge && double(m->nnz) / nt < 0.5 * cap) return KMCF_OK;
+    if (getenv("KMCF_SPMV_VERBOSE"))
+        fprintf(stderr, "kmcf window plan: %d tiles, %.1f rows, %.1f nnz, %.1f window columns per tile\n", nt, double(n) / nt,
+                double(m->nnz) / nt, double(wcol.size()) / nt);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tile), tiles.size() * sizeof(int2)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_wcol), std::max<size_t>(wcol.size(), 1) * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_idx16), idx.size() * sizeof(unsigned short)));
+    KMCF_HIP(hipMemcpy(m->d_tile, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_wcol, wcol.data(), wcol.size() * sizeof(int), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_idx16, idx.data(), idx.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    m->n_tiles = nt;
+    m->spmv_wmax = wmax;
+    *ok = true;
+    return KMCF_OK;
 }
 
 }  // namespace
@@ -302,7 +500,24 @@ int kmcf_spmv_plan(kmcf_matrix *m)
     m->spmv_u = u;
     m->spmv_lpr2 = env_int("KMCF_SPMV_LPR2", 4);
     const int cap = KMCF_BLOCK * u;
-    int kind = env_int("KMCF_SPMV_KIND", 1);
+    // kind: window kernel unless the plan declines (scattered columns, very long rows), then stream, then vec
+    int kind = env_int("KMCF_SPMV_KIND", -1);
+    const bool judge = kind < 0;
+    if (kind < 0 || kind > 2) kind = 2;
+    if (kind == 2) {
+        int wq = env_int("KMCF_SPMV_WQ", 3);
+        if (wq != 2 && wq != 3 && wq != 4) wq = 3;
+        const int uw = (u == 4 && wq == 2) ? 4 : 8;      // instantiated (U, WQ) pairs: see launch_interior
+        bool ok = false;
+        KMCF_TRY(plan_window(m, uw, wq, judge, &ok));
+        if (ok) {
+            m->spmv_u = uw;
+            m->spmv_kind = 2;
+            m->spmv_grid = window_grid(m);
+            return KMCF_OK;
+        }
+        kind = 1;
+    }
     std::vector<int> chunk_row;
     if (kind == 1) {
         const std::vector<int> &rp = m->h_row_ptr;
@@ -400,6 +615,35 @@ extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms
     return KMCF_OK;
 }
 
+// Times the pieces of one distributed CG iteration separately (diagnostic for bench.py at N > 1; every
+// rank must call it with the same arguments): kind 0 = all-reduce of 3 doubles, 1 = halo exchange alone
+// (pack, send/recv, wait), 2 = the SpMV kernels alone (interior + boundary rows, no exchange).
+extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_total)
+{
+    KMCF_CHECK(m && reps > 0 && ms_total && kind >= 0 && kind <= 2, KMCF_ERR_ARG, "kmcf_comm_bench: bad argument");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_comm_bench: host-only matrix");
+    kmcf_comm *c = m->comm;
+    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_HIP(hipMemsetAsync(&m->d_S->red[0], 0, 3 * sizeof(double), c->stream));
+    KMCF_HIP(hipEventRecord(c->ev_t0, c->stream));
+    for (int i = 0; i < reps; ++i) {
+        if (kind == 0) {
+            KMCF_TRY(kmcf_comm_allreduce_sum(c, &m->d_S->red[0], 3));
+        } else if (kind == 1) {
+            KMCF_TRY(kmcf_halo_exchange_begin(m));
+            KMCF_TRY(kmcf_halo_exchange_end(m));
+        } else {
+            launch_interior(m, true, false);
+            if (m->n_halo > 0 && m->n_boundary_rows > 0) launch_vec_any(m, true, false, true);
+            KMCF_HIP(hipGetLastError());
+        }
+    }
+    KMCF_HIP(hipEventRecord(c->ev_t1, c->stream));
+    KMCF_HIP(hipEventSynchronize(c->ev_t1));
+    KMCF_HIP(hipEventElapsedTime(ms_total, c->ev_t0, c->ev_t1));
+    return KMCF_OK;
+}
+
 // Re-plan the SpMV of an existing matrix from the KMCF_SPMV_* environment (tuning aid).
 extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
 {
@@ -407,6 +651,10 @@ extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
     KMCF_HIP(hipSetDevice(m->comm->device));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->d_chunk_row) { hipFree(m->d_chunk_row); m->d_chunk_row = nullptr; }
+    if (m->d_tile) { hipFree(m->d_tile); m->d_tile = nullptr; }
+    if (m->d_wcol) { hipFree(m->d_wcol); m->d_wcol = nullptr; }
+    if (m->d_idx16) { hipFree(m->d_idx16); m->d_idx16 = nullptr; }
+    m->n_tiles = 0;
     return kmcf_spmv_plan(m);
 }
 

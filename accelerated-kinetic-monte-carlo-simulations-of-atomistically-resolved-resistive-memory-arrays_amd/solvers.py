@@ -434,6 +434,12 @@ class Distributed_matrix:
                  "kmcf_spmv_bench")
         return ms.value
 
+    def comm_bench(self, kind, reps):
+        """ms for `reps` x {0: all-reduce of 3 doubles, 1: halo exchange, 2: SpMV kernels without exchange}."""
+        ms = C.c_float()
+        _L.check(self.lib.kmcf_comm_bench(self.handle, int(kind), int(reps), C.byref(ms)), "kmcf_comm_bench")
+        return ms.value
+
     def close(self):
         if self.owned and self.handle:
             self.lib.kmcf_matrix_destroy(self.handle)

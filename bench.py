@@ -130,6 +130,16 @@ def main():
                 "kernel": "spmv_stream_kernel (CSR SpMV + fused p.Ap)", "us_per_launch": round(spmv_us, 2),
                 "algorithmic_bytes_per_launch": int(alg_bytes)}
 
+    # multi-rank diagnostic: the pieces of one distributed iteration timed separately (rank 0's clock)
+    diag = None
+    if world > 1:
+        reps = 200
+        diag = {}
+        for kind, key in ((0, "allreduce3_us"), (1, "halo_exchange_us"), (2, "spmv_kernels_us")):
+            mat.comm_bench(kind, 10)
+            diag[key] = round(mat.comm_bench(kind, reps) * 1e3 / reps, 2)
+        diag["cg_variant"] = os.environ.get("KMCF_CG_VARIANT", "cg1r")
+
     # HBM traffic of that kernel from rocprofv3 PMC runs (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # corrections applied by tools/pmc_summary.py); measured offline on this workload, committed under
     # profiles/, and only reported when it was taken on the same matrix
@@ -175,6 +185,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if diag is not None:
+            out["diag"] = diag
         if args.workload == "5nm":
             out["data"] = "reference 5nm_device (fixture)"
         print(json.dumps(out))

@@ -126,6 +126,13 @@ int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap);
  * events on that stream; *ms_total receives the elapsed time. */
 int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms_total);
 
+/* Diagnostic for multi-rank runs (collective: same arguments on every rank):
+ * times `reps` repetitions of one piece of a distributed CG iteration on the
+ * compute stream -- kind 0: the all-reduce of the 3 fused scalars, 1: the halo
+ * exchange alone (pack, send/recv, wait), 2: the SpMV kernels alone (interior
+ * + boundary rows, no exchange). */
+int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_total);
+
 typedef struct {
     int iterations;       /* CG iterations executed (reference prints K = iterations+1) */
     int converged;        /* 1 if the stopping rule was met                             */

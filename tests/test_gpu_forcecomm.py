@@ -34,7 +34,10 @@ st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d
                                        d["nn_dist"], len(d["metals"]), 0)
 S.sum_and_gather_potential(buf, NL, comm)
 v = buf.site_potential_boundary.cpu().numpy()
-print("RESULT " + json.dumps(dict(st=st, vsum=float(np.abs(v).sum()), charged=int((buf.site_charge != 0).sum().item()))))
+mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
+tb = [mat.comm_bench(kind, 20) for kind in (0, 1, 2)]        # bench.py's N>1 diagnostic
+print("RESULT " + json.dumps(dict(st=st, vsum=float(np.abs(v).sum()), charged=int((buf.site_charge != 0).sum().item()),
+                                  tb=tb)))
 """ % ROOT
 
 
@@ -58,3 +61,4 @@ def test_forced_collectives_match_plain_path():
     assert forced["st"]["relres"] == pytest.approx(plain["st"]["relres"], rel=1e-12)
     assert forced["vsum"] == pytest.approx(plain["vsum"], rel=1e-12)
     assert forced["charged"] == plain["charged"] == 339
+    assert all(t >= 0.0 for t in forced["tb"]) and forced["tb"][2] > 0.0

@@ -192,7 +192,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     // partial sources: local partial arrays, or the all-reduced scalar in S->red
     part_ref prz_loc{m->d_part_b, vg, nullptr, 0};
     part_ref pbb_loc{m->d_part_c, vg, nullptr, 0};
-    part_ref ppap_loc{m->d_part_a, m->spmv_grid, m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
+    part_ref ppap_loc{m->d_part_a, kmcf_interior_grid(m), m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
     part_ref prz = multi ? part_ref{&S->red[0], 1, nullptr, 0} : prz_loc;
     part_ref pbb = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pbb_loc;
     part_ref ppap = multi ? part_ref{&S->red[2], 1, nullptr, 0} : ppap_loc;
@@ -379,7 +379,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
     }
     part_ref pg_loc{m->d_part_b, vg, nullptr, 0};
     part_ref pb_loc{m->d_part_c, vg, nullptr, 0};
-    part_ref pd_loc{m->d_part_a, m->spmv_grid, m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
+    part_ref pd_loc{m->d_part_a, kmcf_interior_grid(m), m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
     part_ref pg = multi ? part_ref{&S->red[0], 1, nullptr, 0} : pg_loc;
     part_ref pd = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pd_loc;
     part_ref pb = multi ? part_ref{&S->red[2], 1, nullptr, 0} : pb_loc;
@@ -510,6 +510,7 @@ int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, dou
     scale_matrix_kernel<<<g * 4, KMCF_BLOCK, 0, c->stream>>>(n, m->d_row_ptr, m->d_col, m->d_val, dis);  // :745
     scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 1);      // start guess (:751)
     KMCF_HIP(hipGetLastError());
+    m->coded = false;             // d_val no longer matches the value codes: SpMV reads d_val from here on
     if (d_rhs_user) KMCF_TRY(kmcf_vec_out(m, d_rhs_user, m->d_r));
     // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
     // the same iterates as r = b - A y, p = r used here.  The unpreconditioned loop never

@@ -264,11 +264,16 @@ int loopback_halo(kmcf_matrix *m)
             rc = KMCF_ERR_COMM;
             break;
         }
-        if (nr && hipMemcpy(m->d_p + m->n_loc + m->halo_offset[k], pm->d_send_buf + pm->send_offset[kk],
-                            nr * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+        // device-to-device copies need not be host-synchronous: enqueue on this rank's stream and wait below
+        if (nr && hipMemcpyAsync(m->d_p + m->n_loc + m->halo_offset[k], pm->d_send_buf + pm->send_offset[kk],
+                                 nr * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
             kmcf_set_error("loopback halo: hipMemcpy failed");
             rc = KMCF_ERR_HIP;
         }
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == KMCF_OK) {
+        kmcf_set_error("loopback halo: stream sync failed");
+        rc = KMCF_ERR_HIP;
     }
     group_barrier(g);                                // peers may repack now
     return rc;
@@ -282,10 +287,11 @@ int loopback_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
     group_barrier(g);
     for (int q = 0; q < g->nranks; ++q) {
         if (q == c->rank || counts[q] == 0) continue;
-        KMCF_HIP(hipMemcpy(static_cast<char *>(d_buf) + (size_t)displs[q] * es,
-                           static_cast<char *>(g->slot[q]) + (size_t)displs[q] * es, (size_t)counts[q] * es,
-                           hipMemcpyDeviceToDevice));
+        KMCF_HIP(hipMemcpyAsync(static_cast<char *>(d_buf) + (size_t)displs[q] * es,
+                                static_cast<char *>(g->slot[q]) + (size_t)displs[q] * es, (size_t)counts[q] * es,
+                                hipMemcpyDeviceToDevice, c->stream));
     }
+    KMCF_HIP(hipStreamSynchronize(c->stream));       // copies landed before any peer overwrites its slot
     group_barrier(g);
     return KMCF_OK;
 }

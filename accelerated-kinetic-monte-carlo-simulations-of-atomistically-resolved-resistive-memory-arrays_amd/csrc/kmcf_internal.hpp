@@ -41,6 +41,9 @@ void kmcf_set_error(const char *fmt, ...);
 constexpr int KMCF_BLOCK = 256;          // 4 wavefronts
 constexpr int KMCF_MAX_PARTIALS = 2048;  // = 256 CUs x 8 resident blocks
 constexpr int KMCF_CHUNK_ITERS = 32;     // CG iterations enqueued between convergence read-backs
+constexpr int KMCF_DICT_MAX = 62;        // value dictionary of the coded window SpMV (codes 0..61)
+constexpr int KMCF_CODE_DIAG = 63;       // code of a row's diagonal entry (value in d_diagv)
+constexpr int KMCF_SLOT_BITS = 10;       // window slots < 1024
 
 // Device-resident CG scalars (never round-trip through the host inside the loop).
 struct kmcf_scalars {
@@ -147,10 +150,27 @@ struct kmcf_matrix {
     int spmv_kind = 0;                 // 0: vec<LPR>, 1: stream (nnz-chunked, LDS row reduction), 2: window
     // window kernel (kind 2): tiles of whole rows whose distinct columns (<= spmv_wmax) are staged in LDS
     int n_tiles = 0;
+    int64_t n_wcols = 0;               // sum of the tiles' window sizes
     int spmv_wmax = 0;
     int2 *d_tile = nullptr;            // (first row, first window slot) per tile, n_tiles + 1
     int *d_wcol = nullptr;             // column of each window slot (ascending inside a tile)
-    unsigned short *d_idx16 = nullptr; // per nnz: window slot of its column inside the tile
+    unsigned short *d_idx16 = nullptr; // per nnz: window slot of its column inside the tile (bits 0-9) | value code (10-15)
+    // Dictionary-coded values (window kernel only): when every off-diagonal value of the matrix is one of
+    // <= KMCF_DICT_MAX distinct doubles (K and the CB-edge system hold two: -high_G, -low_G), the slot stream
+    // carries the value's dictionary code and the SpMV does not read d_val at all: 2 B/nnz instead of 10.
+    // Diagonal entries carry code KMCF_CODE_DIAG and are taken from d_diagv.  Lossless: same doubles, same
+    // products; only the diagonal product is added last instead of in column order.
+    bool coded = false;                // codes + d_diagv + d_dict currently match d_val
+    bool expect_coded = true;          // plan hint: tiles sized for the coded kernel (<= 8*U rows: full passes)
+    double *d_dict = nullptr;          // KMCF_DICT_MAX + 1 doubles
+    double *d_diagv = nullptr;         // diagonal value per row (0 where a row has no diagonal entry)
+    int *d_diag_pos = nullptr;         // nnz index of each row's diagonal entry, -1 if none
+    int *d_code_fail = nullptr;        // encode kernel: set when a value is not in the dictionary
+    std::vector<int> h_diag_pos;
+    double h_dict[64] = {0.0};         // host copy of d_dict (lives as long as the matrix: async upload source)
+    bool dict_uploaded = false;
+    int dict_n = 0;                    // dictionary entries in use (<= 2: register variant of the coded kernel)
+    int spmv_grid_coded = 0;           // interior grid while coded (its kernel's residency differs)
     int spmv_u = 8;                    // stream: nnz per thread per chunk
     int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction
     int n_chunks = 0;
@@ -176,11 +196,24 @@ struct kmcf_kstate {
     double *d_gather = nullptr;
 };
 
+// grid of the interior SpMV pass = number of p.Ap partials it writes
+inline int kmcf_interior_grid(const kmcf_matrix *m)
+{
+    return (m->spmv_kind == 2 && m->coded) ? m->spmv_grid_coded : m->spmv_grid;
+}
+
 // ---------------------------------------------------------------- internal entry points
 // spmv.hip
 int kmcf_spmv_plan(kmcf_matrix *m);
 // Ap = A*p on m->d_p (already holding local p), writes m->d_Ap and pAp partials.
 int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done);
+// Dictionary-code the values now in d_val (window kernel only; no-op otherwise).  h_dict/nd: the distinct
+// off-diagonal values; m->coded is set iff every off-diagonal value was found.  Synchronous.
+int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd);
+// Host scan of internal-order values for their distinct off-diagonal values, then kmcf_matrix_encode_values.
+int kmcf_matrix_encode_from_host(kmcf_matrix *m, const double *h_val_internal);
+// For producers that write codes and d_diagv themselves (K assembly): install the dictionary, mark coded.
+int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd);
 // cg.hip
 int kmcf_halo_exchange_begin(kmcf_matrix *m);   // pack + send/recv on the comm stream
 int kmcf_halo_exchange_end(kmcf_matrix *m);     // compute stream waits for the halo

@@ -249,8 +249,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
     const int *__restrict__ right_row_ptr, const int *__restrict__ right_col,
     const unsigned char *__restrict__ cls, double high_G, double low_G, double VL, double VR,
     double *__restrict__ diag_out, double *__restrict__ left_out, double *__restrict__ right_out,
-    double *__restrict__ dinv_out, double *__restrict__ rhs_out)
+    double *__restrict__ dinv_out, double *__restrict__ rhs_out,
+    unsigned short *__restrict__ idx16 /* window SpMV: value codes above the slot bits, or nullptr */,
+    double *__restrict__ diagv /* window SpMV: diagonal per row, or nullptr */)
 {
+    constexpr int SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
     constexpr int RPB = KMCF_BLOCK / LPR;
     const int lane = threadIdx.x % LPR;
     const int groups = (n_loc + RPB - 1) / RPB;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
                 const int site = (c < n_loc) ? (row_site0 + (perm ? perm[c] : c)) : (n_left + halo_gid[c - n_loc]);
                 const bool high = high_rule<CB>(ci, cls[site]);
                 val[j] = high ? -high_G : -low_G;
+                if (idx16) idx16[j] = (unsigned short)((idx16[j] & SLOT_MASK) | ((high ? 0 : 1) << KMCF_SLOT_BITS));
                 nh += high; nl += !high;
             }
             for (int j = left_row_ptr[ru] + lane; j < left_row_ptr[ru + 1]; j += LPR) {
@@ -291,7 +295,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
             const double l = (double)lh * high_G + (double)ll * low_G;
             const double rr = (double)rh * high_G + (double)rl * low_G;
             const double tot = d + l + rr;                 // insert_into_diag :807
-            if (dpos >= 0) val[dpos] = tot;
+            if (dpos >= 0) {
+                val[dpos] = tot;
+                if (idx16) idx16[dpos] = (unsigned short)((idx16[dpos] & SLOT_MASK) | (KMCF_CODE_DIAG << KMCF_SLOT_BITS));
+            }
+            if (diagv) diagv[r] = dpos >= 0 ? tot : 0.0;
             diag_out[r] = tot;
             left_out[r] = l;
             right_out[r] = rr;
@@ -602,7 +610,7 @@ extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *
 #define KMCF_ASM_ARGS(VL, VR)                                                                                          \
     m->n_loc, k->N_left + m->row0, k->N_left, k->N_interface, m->d_row_ptr, m->d_col, m->d_val, k->d_diag_pos,          \
         m->d_halo_gid, m->d_perm, k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls,      \
-        high_G, low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs
+        high_G, low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs, code_idx, code_diag
 
 static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
                             const int *d_metals, int num_metals, double Vd, double high_G, double low_G,
@@ -615,6 +623,12 @@ static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int
     if (m->n_loc > 0) {
         constexpr int LPR = 16;
         const int grid = grid1d((int64_t)m->n_loc * LPR);
+        // window SpMV: the off-diagonals are -high_G / -low_G, so the assembly writes their dictionary codes
+        // next to the values and the CG's SpMV streams 2 B/nnz (kmcf_internal.hpp, kmcf_matrix::coded)
+        const double dict[2] = {-high_G, -low_G};
+        KMCF_TRY(kmcf_matrix_set_dictionary(m, dict, 2));
+        unsigned short *code_idx = m->coded ? m->d_idx16 : nullptr;
+        double *code_diag = m->coded ? m->d_diagv : nullptr;
         if (!cb_rule)
             k_assemble_kernel<LPR, false><<<grid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASM_ARGS(-Vd / 2, Vd / 2));   // :866-867
         else

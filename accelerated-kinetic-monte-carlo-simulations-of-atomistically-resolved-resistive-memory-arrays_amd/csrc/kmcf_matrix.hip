@@ -237,7 +237,28 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     KMCF_TRY(dev_alloc(&m->d_part_b, (size_t)KMCF_MAX_PARTIALS));
     KMCF_TRY(dev_alloc(&m->d_part_c, (size_t)KMCF_MAX_PARTIALS));
     KMCF_TRY(dev_alloc(&m->d_S, 1));
+    // Plan hint: a matrix created without values is filled by the K assembly (two off-diagonal values, always
+    // coded); one created with values is coded iff its off-diagonals take few distinct values.
+    m->expect_coded = true;
+    if (h_val) {
+        long long dict[KMCF_DICT_MAX];
+        int nd = 0, last = -1;
+        for (int i = 0; i < n_loc && m->expect_coded; ++i)
+            for (int j = rp[i]; j < rp[i + 1]; ++j) {
+                if (col_local[j] == i) continue;
+                long long b;
+                memcpy(&b, &val_int[j], sizeof(b));
+                if (last >= 0 && dict[last] == b) continue;
+                int k = 0;
+                while (k < nd && dict[k] != b) ++k;
+                last = k;
+                if (k < nd) continue;
+                if (nd == KMCF_DICT_MAX) { m->expect_coded = false; break; }
+                dict[nd++] = b;
+            }
+    }
     KMCF_TRY(kmcf_spmv_plan(m));
+    if (h_val) KMCF_TRY(kmcf_matrix_encode_from_host(m, val_int.data()));
     *out = m;
     return KMCF_OK;
 }
@@ -305,7 +326,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,
-                        m->d_tile, m->d_wcol, m->d_idx16};
+                        m->d_tile, m->d_wcol, m->d_idx16, m->d_dict, m->d_diagv, m->d_diag_pos, m->d_code_fail};
         for (void *p : ptrs)
             if (p) hipFree(p);
     }
@@ -323,6 +344,10 @@ extern "C" int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info)
     info->halo_cols = m->n_halo;
     info->send_rows = m->n_send;
     info->boundary_rows = m->n_boundary_rows;
+    info->spmv_kind = m->spmv_kind;
+    info->spmv_coded = (m->spmv_kind == 2 && m->coded) ? 1 : 0;
+    info->spmv_tiles = m->spmv_kind == 2 ? m->n_tiles : 0;
+    info->spmv_window_cols = m->spmv_kind == 2 ? m->n_wcols : 0;
     return KMCF_OK;
 }
 
@@ -347,6 +372,7 @@ extern "C" int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val)
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->h_perm.empty()) {
         KMCF_HIP(hipMemcpy(m->d_val, h_val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+        KMCF_TRY(kmcf_matrix_encode_from_host(m, h_val));
     } else {
         // creation order -> internal order, row by row (entries keep their order inside a row)
         std::vector<double> v((size_t)m->nnz);
@@ -356,6 +382,7 @@ extern "C" int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val)
             if (len) memcpy(&v[m->h_row_ptr[i]], &h_val[m->h_row_ptr_user[r]], (size_t)len * sizeof(double));
         }
         KMCF_HIP(hipMemcpy(m->d_val, v.data(), (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+        KMCF_TRY(kmcf_matrix_encode_from_host(m, v.data()));
     }
     return KMCF_OK;
 }

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "kmcf_internal.hpp"
 
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
 }
 
 // ------------------------------------------------------------------ window kernel
-// Tiles of whole rows (<= 256*U nnz) whose distinct columns (<= 256*WQ of them, found at plan time) are
-// staged once in LDS: the tile's window map is read coalesced, x is fetched run by run (neighbouring lanes
-// read neighbouring addresses, so the texture path merges them), and the per-entry gather happens in LDS
-// through 16-bit window slots instead of one L1 tag lookup per lane (PMC: 45.6 M TCP accesses per launch
+// Tiles of whole rows (<= 256*U nnz, <= 8*U rows) whose distinct columns (<= 256*WQ of them, found at plan
+// time) are staged once in LDS: the tile's window map is read coalesced, x is fetched run by run (neighbouring
+// lanes read neighbouring addresses, so the texture path merges them), and the per-entry gather happens in
+// LDS through 16-bit window slots instead of one L1 tag lookup per lane (PMC: 45.6 M TCP accesses per launch
 // for the stream kernel, most of them single-lane gathers).  Values keep their CSR order and stay f64.
 template <int U, int WQ, int LPR2, bool DOT, bool SKIP_BOUNDARY>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = u * KMCF_BLOCK + tid;
-            if (i < cnt) prod[i] = v[u] * xw[ci[u]];
+            if (i < cnt) prod[i] = v[u] * xw[ci[u] & ((1 << KMCF_SLOT_BITS) - 1)];   // code bits may be stale
         }
         __syncthreads();
         constexpr int RPP = KMCF_BLOCK / LPR2;  // rows per pass
@@ -187,6 +188,95 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
             if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
                 y[rr] = s;
                 if (DOT) dot += x[rr] * s;
+            }
+        }
+        __syncthreads();
+    }
+    if (DOT) {
+        double t = block_sum_256(dot, lds4);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ coded window kernel
+// Same tiles, for matrices whose off-diagonal values are all one of <= 62 doubles (K and the CB-edge system:
+// two, -high_G and -low_G): idx16 carries the value's dictionary code above the slot bits and the kernel
+// never reads val -- 2 B/nnz of matrix stream.  Only the 16-bit stream is parked in LDS (not products): the
+// row lanes read slot+code, pick the value (ND <= 2: two registers; else an LDS dictionary), fetch x from the
+// window and accumulate in the same order as the other kernels.  The diagonal entry (code 63, skipped in the
+// stream) comes from diagv and is added after the off-diagonal sum.
+template <int U, int WQ, int ND, bool DOT, bool SKIP_BOUNDARY>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
+    int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
+    const unsigned short *__restrict__ idx16, const double *__restrict__ x, double *__restrict__ y,
+    const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S,
+    int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
+{
+    constexpr int LPR2 = 4, RPP = KMCF_BLOCK / LPR2, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
+    __shared__ double xw[KMCF_BLOCK * WQ];
+    __shared__ unsigned short sidx[KMCF_BLOCK * U];
+    __shared__ double lds4[4];
+    __shared__ double sdict[ND > 2 ? 64 : 1];
+    if (check_done && S->done) return;
+    const int tid = threadIdx.x;
+    double d0 = 0.0, d1 = 0.0;
+    if (ND <= 2) { d0 = dict[0]; d1 = dict[1]; }
+    else if (tid < 64) sdict[tid] = dict[tid];          // visible after the first tile's barrier
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Cx = (n_tiles + 7) >> 3;  // tiles per XCD
+    const int lane = tid % LPR2;
+    double dot = 0.0;
+    for (int g = bi; g < Cx; g += nb8) {
+        const int c = xcd * Cx + g;
+        if (c >= n_tiles) break;                       // block-uniform
+        const int2 t0 = tile[c], t1 = tile[c + 1];
+        const int r0 = t0.x, r1 = t1.x, w0 = t0.y, W = t1.y - w0;
+        const int base = row_ptr[r0];
+        const int cnt = row_ptr[r1] - base;
+        int wc[WQ];
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int w = q * KMCF_BLOCK + tid;
+            wc[q] = w < W ? __builtin_nontemporal_load(wcol + w0 + w) : -1;
+        }
+        unsigned short ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * KMCF_BLOCK + tid;
+            ci[u] = i < cnt ? __builtin_nontemporal_load(idx16 + base + i) : (unsigned short)0;
+        }
+        // row bounds of the first pass while the loads are in flight
+        int rr = r0 + tid / LPR2;
+        int b = 0, e = 0;
+        if (rr < r1) { b = row_ptr[rr] - base; e = row_ptr[rr + 1] - base; }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wc[q] >= 0) xw[q * KMCF_BLOCK + tid] = x[wc[q]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sidx[u * KMCF_BLOCK + tid] = ci[u];
+        __syncthreads();
+        const int passes = (r1 - r0 + RPP - 1) / RPP;
+        for (int ps = 0; ps < passes; ++ps) {
+            if (ps > 0) {
+                rr = r0 + ps * RPP + tid / LPR2;
+                b = e = 0;
+                if (rr < r1) { b = row_ptr[rr] - base; e = row_ptr[rr + 1] - base; }
+            }
+            const bool valid = rr < r1;
+            double s = 0.0;
+            for (int j = b + lane; j < e; j += LPR2) {
+                const int cc = sidx[j];
+                const int code = cc >> KMCF_SLOT_BITS;
+                const double xv = xw[cc & SLOT_MASK];
+                const double v = ND <= 2 ? (code == 0 ? d0 : d1) : sdict[code];
+                s += code == KMCF_CODE_DIAG ? 0.0 : v * xv;
+            }
+            s = wave_sum_width(s, LPR2);
+            if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
+                const double xr = x[rr];
+                s += diagv[rr] * xr;
+                y[rr] = s;
+                if (DOT) dot += xr * s;
             }
         }
         __syncthreads();
@@ -329,7 +419,7 @@ void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     hipStream_t st = m->comm->stream;
     const int chk = (skip_if_done ? 1 : 0) | (getenv("KMCF_SPMV_MAP") ? 2 : 0);
-    const int grid = m->spmv_grid;
+    const int grid = kmcf_interior_grid(m);
     const bool skipb = (m->n_halo > 0);
     if (with_dot) {
         if (skipb) spmv_stream_kernel<U, LPR2, true, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, m->d_part_a));
@@ -342,48 +432,79 @@ void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 
 #define KMCF_WINDOW_ARGS(isb, part) \
     m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_val, m->d_p, m->d_Ap, isb, part, m->d_S, chk
+#define KMCF_WCODE_ARGS(isb, part) \
+    m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_p, m->d_Ap, isb, part, m->d_S, chk, m->d_dict, m->d_diagv
 
+template <typename K, typename... A>
+void run_or_query(K kernel, bool launch, int *per_cu, int grid, hipStream_t st, A... args)
+{
+    if (launch) kernel<<<grid, KMCF_BLOCK, 0, st>>>(args...);
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, KMCF_BLOCK, 0) != hipSuccess) *per_cu = 0;
+}
+
+// One place that names every window-kernel instance.  which: 0 plain (values streamed), 1 coded with <= 2
+// dictionary values, 2 coded with an LDS dictionary.  launch = false: return the resident blocks per CU of
+// that instance instead of launching it.
 template <int U, int WQ>
-void launch_window(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool skip_if_done)
 {
     hipStream_t st = m->comm->stream;
     const int chk = skip_if_done ? 1 : 0;
-    int grid = m->spmv_grid;
-    if (!with_dot && getenv("KMCF_SPMV_GRIDX")) grid = (std::min(atoi(getenv("KMCF_SPMV_GRIDX")), m->n_tiles) + 7) / 8 * 8;  // lab
     const bool skipb = (m->n_halo > 0);
-    if (with_dot) {
-        if (skipb) spmv_window_kernel<U, WQ, 4, true, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(m->d_is_boundary, m->d_part_a));
-        else spmv_window_kernel<U, WQ, 4, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(nullptr, m->d_part_a));
+    const unsigned char *isb = skipb ? m->d_is_boundary : nullptr;
+    double *part = with_dot ? m->d_part_a : nullptr;
+    const int grid = launch ? kmcf_interior_grid(m) : 0;
+    int pc = 0;
+    if (which == 0) {
+        if (with_dot) {
+            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, true, true>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
+            else run_or_query(spmv_window_kernel<U, WQ, 4, true, false>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
+        } else {
+            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, false, true>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
+            else run_or_query(spmv_window_kernel<U, WQ, 4, false, false>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
+        }
+    } else if (which == 1) {
+        if (with_dot) {
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 2, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, 2, true, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+        } else {
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 2, false, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, 2, false, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+        }
     } else {
-        if (skipb) spmv_window_kernel<U, WQ, 4, false, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(m->d_is_boundary, nullptr));
-        else spmv_window_kernel<U, WQ, 4, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_WINDOW_ARGS(nullptr, nullptr));
+        if (with_dot) {
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 64, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, 64, true, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+        } else {
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 64, false, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, 64, false, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+        }
     }
+    return pc;
 }
 
-// The window kernel walks its tiles in a static loop, so its grid must be exactly what the chip holds at
-// once: with more blocks than resident slots the surplus ones start only after a first-wave block has
-// finished its whole loop (measured 116 us at 2048 blocks vs 102 us at 7 blocks x 256 CUs).
-template <int U, int WQ>
-int window_resident_blocks(bool skipb, int device)
+int window_dispatch_any(kmcf_matrix *m, int which, bool launch, bool with_dot, bool skip_if_done)
 {
-    int per_cu = 0, cus = 0;
-    hipError_t e = skipb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spmv_window_kernel<U, WQ, 4, true, true>, KMCF_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spmv_window_kernel<U, WQ, 4, true, false>, KMCF_BLOCK, 0);
-    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    return per_cu * cus;
-}
-
-int window_grid(kmcf_matrix *m)
-{
-    const bool skipb = (m->n_halo > 0);
-    const int dev = m->comm->device;
-    int resident = 0;
     switch (m->spmv_u * 100 + m->spmv_wmax / KMCF_BLOCK) {
-        case 402: resident = window_resident_blocks<4, 2>(skipb, dev); break;
-        case 802: resident = window_resident_blocks<8, 2>(skipb, dev); break;
-        case 804: resident = window_resident_blocks<8, 4>(skipb, dev); break;
-        default: resident = window_resident_blocks<8, 3>(skipb, dev); break;
+        case 402: return window_dispatch<4, 2>(m, which, launch, with_dot, skip_if_done);
+        case 802: return window_dispatch<8, 2>(m, which, launch, with_dot, skip_if_done);
+        case 804: return window_dispatch<8, 4>(m, which, launch, with_dot, skip_if_done);
+        case 1603: return window_dispatch<16, 3>(m, which, launch, with_dot, skip_if_done);
+        case 1604: return window_dispatch<16, 4>(m, which, launch, with_dot, skip_if_done);
+        default: return window_dispatch<8, 3>(m, which, launch, with_dot, skip_if_done);
     }
+}
+
+// The window kernels walk their tiles in a static loop, so the grid must be exactly what the chip holds at
+// once: with more blocks than resident slots the surplus ones start only after a first-wave block has
+// finished its whole loop (measured 116 us at 2048 blocks vs 102 us at 7 blocks x 256 CUs; 108 vs 72 us
+// for the coded kernel when 512 B more LDS dropped it from 7 to 6 blocks per CU under an unchanged grid).
+int window_grid(kmcf_matrix *m, int which)
+{
+    int cus = 0;
+    const int per_cu = window_dispatch_any(m, which, false, true, false);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->comm->device) != hipSuccess) cus = 0;
+    const int resident = per_cu * cus;
     int g = grid_for(m->n_tiles, 1);
     if (resident >= 8 && g > resident) g = resident / 8 * 8;
     return g;
@@ -392,13 +513,7 @@ int window_grid(kmcf_matrix *m)
 void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     if (m->spmv_kind == 2) {
-        const int key = m->spmv_u * 100 + m->spmv_wmax / KMCF_BLOCK;
-        switch (key) {
-            case 402: launch_window<4, 2>(m, with_dot, skip_if_done); break;
-            case 802: launch_window<8, 2>(m, with_dot, skip_if_done); break;
-            case 804: launch_window<8, 4>(m, with_dot, skip_if_done); break;
-            default: launch_window<8, 3>(m, with_dot, skip_if_done); break;
-        }
+        window_dispatch_any(m, m->coded ? (m->dict_n <= 2 ? 1 : 2) : 0, true, with_dot, skip_if_done);
     } else if (m->spmv_kind == 1) {
         const int key = m->spmv_u * 100 + m->spmv_lpr2;
         switch (key) {
@@ -420,17 +535,23 @@ int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-// Cuts the rows into tiles for the window kernel: whole rows, at most 256*u entries and 256*wq distinct
-// columns per tile (compact-halo column ids, so halo slots are window columns like any other).  *ok stays
-// false (nothing allocated) if a row does not fit a tile or, with `judge`, if the tiles come out less than
-// half full: columns too scattered for a window, the stream kernel's direct gathers serve those better.
+// Cuts the rows into tiles for the window kernels: whole rows, at most 256*u entries, 8*u rows (u/8 full
+// passes of the 4-lanes-per-row reduction) and 256*wq distinct columns per tile (compact-halo column ids, so
+// halo slots are window columns like any other).  *ok stays false (nothing allocated) if a row does not fit
+// a tile or, with `judge`, if a window column is used by fewer than two entries on average: columns too
+// scattered for a window to pay off, the stream kernel's direct gathers serve those better (K: ~5 entries
+// per window column).
 int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 {
     *ok = false;
     const int n = m->n_loc;
     if (n == 0 || m->nnz == 0) return KMCF_OK;
     const std::vector<int> &rp = m->h_row_ptr;
-    const int cap = KMCF_BLOCK * u, wmax = KMCF_BLOCK * wq;
+    // the row limit serves the coded kernel (full passes of its row lanes); the plain kernel, whose cost is
+    // the value stream, prefers tiles filled to the entry limit
+    const char *ce = getenv("KMCF_SPMV_CODED");
+    const bool for_coded = m->expect_coded && !(ce && atoi(ce) == 0);
+    const int cap = KMCF_BLOCK * u, wmax = KMCF_BLOCK * wq, row_cap = for_coded ? 8 * u : n;
     std::vector<int> col((size_t)m->nnz);
     KMCF_HIP(hipMemcpy(col.data(), m->d_col, col.size() * sizeof(int), hipMemcpyDeviceToHost));
     std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1);
@@ -441,7 +562,7 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     while (r < n) {
         uniq.clear();
         int e = r;
-        while (e < n && rp[e + 1] - rp[r] <= cap) {
+        while (e < n && e - r < row_cap && rp[e + 1] - rp[r] <= cap) {
             const size_t before = uniq.size();
             for (int j = rp[e]; j < rp[e + 1]; ++j)
                 if (slot[col[j]] < 0) { slot[col[j]] = 0; uniq.push_back(col[j]); }
@@ -463,7 +584,7 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     }
     tiles.push_back(make_int2(n, (int)wcol.size()));
     const int nt = (int)tiles.size() - 1;
-    if (judge && double(m->nnz) / nt < 0.5 * cap) return KMCF_OK;
+    if (judge && double(m->nnz) < 2.0 * double(wcol.size())) return KMCF_OK;
     if (getenv("KMCF_SPMV_VERBOSE"))
         fprintf(stderr, "kmcf window plan: %d tiles, %.1f rows, %.1f nnz, %.1f window columns per tile\n", nt, double(n) / nt,
                 double(m->nnz) / nt, double(wcol.size()) / nt);
@@ -474,9 +595,54 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     KMCF_HIP(hipMemcpy(m->d_wcol, wcol.data(), wcol.size() * sizeof(int), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(m->d_idx16, idx.data(), idx.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     m->n_tiles = nt;
+    m->n_wcols = (int64_t)wcol.size();
     m->spmv_wmax = wmax;
+    // diagonal positions and the buffers of the dictionary-coded variant (codes are written later, by
+    // kmcf_matrix_encode_values or by the K assembly)
+    m->h_diag_pos.assign((size_t)n, -1);
+    for (int i = 0; i < n; ++i)
+        for (int j = rp[i]; j < rp[i + 1]; ++j)
+            if (col[j] == i) { m->h_diag_pos[i] = j; break; }
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_diag_pos), (size_t)n * sizeof(int)));
+    KMCF_HIP(hipMemcpy(m->d_diag_pos, m->h_diag_pos.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_dict), 64 * sizeof(double)));
+    KMCF_HIP(hipMemset(m->d_dict, 0, 64 * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_diagv), (size_t)n * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_code_fail), sizeof(int)));
+    m->coded = false;
     *ok = true;
     return KMCF_OK;
+}
+
+// Writes the dictionary code of every entry above its slot bits and the per-row diagonal value.
+template <int LPR>
+__global__ __launch_bounds__(KMCF_BLOCK) void encode_values_kernel(int n, const int *__restrict__ row_ptr,
+                                                                   const int *__restrict__ diag_pos,
+                                                                   const double *__restrict__ val,
+                                                                   const double *__restrict__ dict, int nd,
+                                                                   unsigned short *__restrict__ idx16,
+                                                                   double *__restrict__ diagv, int *__restrict__ fail)
+{
+    __shared__ double sdict[64];
+    if (threadIdx.x < 64) sdict[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+    constexpr int RPB = KMCF_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    for (int r = blockIdx.x * RPB + threadIdx.x / LPR; r < n; r += gridDim.x * RPB) {
+        const int dp = diag_pos[r];
+        if (lane == 0) diagv[r] = dp >= 0 ? val[dp] : 0.0;
+        for (int j = row_ptr[r] + lane; j < row_ptr[r + 1]; j += LPR) {
+            int code = KMCF_CODE_DIAG;
+            if (j != dp) {
+                const double v = val[j];
+                code = -1;
+                for (int k = 0; k < nd; ++k)       // bit pattern, not ==: -0.0 and NaNs stay what they are
+                    if (__double_as_longlong(sdict[k]) == __double_as_longlong(v)) { code = k; break; }
+                if (code < 0) { *fail = 1; code = 0; }
+            }
+            idx16[j] = (unsigned short)((idx16[j] & ((1 << KMCF_SLOT_BITS) - 1)) | (code << KMCF_SLOT_BITS));
+        }
+    }
 }
 
 }  // namespace
@@ -507,13 +673,15 @@ int kmcf_spmv_plan(kmcf_matrix *m)
     if (kind == 2) {
         int wq = env_int("KMCF_SPMV_WQ", 3);
         if (wq != 2 && wq != 3 && wq != 4) wq = 3;
-        const int uw = (u == 4 && wq == 2) ? 4 : 8;      // instantiated (U, WQ) pairs: see launch_interior
+        // instantiated (U, WQ) pairs: window_dispatch_any
+        const int uw = (u == 4 && wq == 2) ? 4 : ((u == 16 && wq >= 3) ? 16 : 8);
         bool ok = false;
         KMCF_TRY(plan_window(m, uw, wq, judge, &ok));
         if (ok) {
             m->spmv_u = uw;
             m->spmv_kind = 2;
-            m->spmv_grid = window_grid(m);
+            m->spmv_grid = window_grid(m, 0);
+            m->spmv_grid_coded = 0;                  // set with the dictionary (kmcf_matrix_set_dictionary)
             return KMCF_OK;
         }
         kind = 1;
@@ -543,6 +711,84 @@ int kmcf_spmv_plan(kmcf_matrix *m)
         m->spmv_grid = grid_for(m->n_loc, KMCF_BLOCK / lpr);
     }
     return KMCF_OK;
+}
+
+static bool coding_enabled(const kmcf_matrix *m)
+{
+    if (m->spmv_kind != 2 || !m->d_idx16) return false;
+    const char *e = getenv("KMCF_SPMV_CODED");
+    return !(e && atoi(e) == 0);
+}
+
+int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
+{
+    m->coded = false;
+    if (!coding_enabled(m)) return KMCF_OK;
+    KMCF_CHECK(nd >= 0 && nd <= KMCF_DICT_MAX, KMCF_ERR_ARG, "value dictionary of %d entries", nd);
+    bool same = true;
+    for (int k = 0; k < 64; ++k) {
+        const double v = k < nd ? h_dict[k] : 0.0;
+        if (memcmp(&m->h_dict[k], &v, sizeof(v)) != 0) { same = false; m->h_dict[k] = v; }
+    }
+    if (!same || !m->dict_uploaded) {
+        KMCF_HIP(hipMemcpyAsync(m->d_dict, m->h_dict, sizeof(m->h_dict), hipMemcpyHostToDevice, m->comm->stream));
+        m->dict_uploaded = true;
+    }
+    const int which = nd <= 2 ? 1 : 2;
+    if (m->dict_n != nd || m->spmv_grid_coded <= 0 || (m->dict_n <= 2 ? 1 : 2) != which)
+        m->spmv_grid_coded = window_grid(m, which);
+    m->dict_n = nd;
+    m->coded = true;
+    return KMCF_OK;
+}
+
+int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd)
+{
+    m->coded = false;
+    if (!coding_enabled(m) || m->n_loc == 0) return KMCF_OK;
+    hipStream_t st = m->comm->stream;
+    KMCF_TRY(kmcf_matrix_set_dictionary(m, h_dict, nd));
+    m->coded = false;
+    KMCF_HIP(hipMemsetAsync(m->d_code_fail, 0, sizeof(int), st));
+    constexpr int LPR = 16;
+    encode_values_kernel<LPR><<<grid_for(m->n_loc, KMCF_BLOCK / LPR), KMCF_BLOCK, 0, st>>>(
+        m->n_loc, m->d_row_ptr, m->d_diag_pos, m->d_val, m->d_dict, nd, m->d_idx16, m->d_diagv, m->d_code_fail);
+    KMCF_HIP(hipGetLastError());
+    int fail = 1;
+    KMCF_HIP(hipMemcpyAsync(&fail, m->d_code_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    KMCF_HIP(hipStreamSynchronize(st));
+    m->coded = (fail == 0);
+    return KMCF_OK;
+}
+
+int kmcf_matrix_encode_from_host(kmcf_matrix *m, const double *h_val_internal)
+{
+    m->coded = false;
+    if (!coding_enabled(m) || m->n_loc == 0) return KMCF_OK;
+    // distinct off-diagonal values (bit patterns); give up at the first one beyond the dictionary size
+    long long dict[KMCF_DICT_MAX];
+    int nd = 0;
+    const std::vector<int> &rp = m->h_row_ptr;
+    int last = -1;
+    for (int i = 0; i < m->n_loc; ++i) {
+        const int dp = m->h_diag_pos[i];
+        for (int j = rp[i]; j < rp[i + 1]; ++j) {
+            if (j == dp) continue;
+            long long b;
+            memcpy(&b, &h_val_internal[j], sizeof(b));
+            if (last >= 0 && dict[last] == b) continue;
+            int k = 0;
+            while (k < nd && dict[k] != b) ++k;
+            if (k == nd) {
+                if (nd == KMCF_DICT_MAX) return KMCF_OK;     // too many distinct values: plain window kernel
+                dict[nd++] = b;
+            }
+            last = k;
+        }
+    }
+    double d[KMCF_DICT_MAX];
+    memcpy(d, dict, sizeof(double) * nd);
+    return kmcf_matrix_encode_values(m, d, nd);
 }
 
 int kmcf_halo_exchange_begin(kmcf_matrix *m)
@@ -654,8 +900,18 @@ extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
     if (m->d_tile) { hipFree(m->d_tile); m->d_tile = nullptr; }
     if (m->d_wcol) { hipFree(m->d_wcol); m->d_wcol = nullptr; }
     if (m->d_idx16) { hipFree(m->d_idx16); m->d_idx16 = nullptr; }
+    if (m->d_dict) { hipFree(m->d_dict); m->d_dict = nullptr; }
+    if (m->d_diagv) { hipFree(m->d_diagv); m->d_diagv = nullptr; }
+    if (m->d_diag_pos) { hipFree(m->d_diag_pos); m->d_diag_pos = nullptr; }
+    if (m->d_code_fail) { hipFree(m->d_code_fail); m->d_code_fail = nullptr; }
     m->n_tiles = 0;
-    return kmcf_spmv_plan(m);
+    m->coded = false;
+    m->dict_uploaded = false;
+    KMCF_TRY(kmcf_spmv_plan(m));
+    // re-code the values now in d_val (tuning aid: a host round trip is fine here)
+    std::vector<double> v((size_t)m->nnz);
+    KMCF_HIP(hipMemcpy(v.data(), m->d_val, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return kmcf_matrix_encode_from_host(m, v.data());
 }
 
 extern "C" int kmcf_pack(kmcf_comm *c, double *d_packed, const double *d_unpacked, const int *d_indices, int n)

@@ -123,12 +123,29 @@ def main():
     mat.spmv_bench(5, True)
     ms = mat.spmv_bench(args.spmv_reps, True)
     spmv_us = ms * 1e3 / args.spmv_reps
-    alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc          # 12 B/nnz + 20 B/row
+    # Algorithmic bytes of one launch = what the kernel's matrix format makes it read and write once
+    # (DESIGN.md 3.1): CSR 12 B/nnz + 20 B/row; window format 10 B/nnz (f64 value + 16-bit
+    # slot) + 4 B per window column + 20 B/row; dictionary-coded window format 2 B/nnz + 4 B per window column
+    # + 28 B/row (row_ptr, diagonal, x, y).  csr_equivalent prices the same launch at the CSR figure.
+    minfo = mat.info()
+    csr_bytes = 12.0 * nnz_loc + 20.0 * n_loc
+    if minfo["spmv_kind"] == 2 and minfo["spmv_coded"]:
+        kname = "spmv_wcode_kernel (window SpMV, dictionary-coded values, fused p.Ap)"
+        alg_bytes = 2.0 * nnz_loc + 4.0 * minfo["spmv_window_cols"] + 28.0 * n_loc
+    elif minfo["spmv_kind"] == 2:
+        kname = "spmv_window_kernel (window SpMV, f64 values, fused p.Ap)"
+        alg_bytes = 10.0 * nnz_loc + 4.0 * minfo["spmv_window_cols"] + 20.0 * n_loc
+    else:
+        kname = "%s (CSR SpMV, fused p.Ap)" % ("spmv_stream_kernel" if minfo["spmv_kind"] == 1 else "spmv_vec_kernel")
+        alg_bytes = csr_bytes
     achieved = alg_bytes / (spmv_us * 1e-6) / 1e9
+    csr_eq = csr_bytes / (spmv_us * 1e-6) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "spmv_stream_kernel (CSR SpMV + fused p.Ap)", "us_per_launch": round(spmv_us, 2),
-                "algorithmic_bytes_per_launch": int(alg_bytes)}
+                "kernel": kname, "us_per_launch": round(spmv_us, 2),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "csr_equivalent": {"bytes_per_launch": int(csr_bytes), "achieved": round(csr_eq, 1),
+                                   "frac": round(csr_eq / HBM_PEAK_GBS, 4)}}
 
     # multi-rank diagnostic: the pieces of one distributed iteration timed separately (rank 0's clock)
     diag = None
@@ -146,7 +163,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if world == 1 and os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("rows") == n_loc and tj.get("workload") == d["name"]:
+        if tj.get("rows") == n_loc and tj.get("workload") == d["name"] and \
+                tj.get("kernel", "").split("<")[0] == kname.split(" ")[0]:
             roofline["traffic"] = tj["corrected_bytes_per_launch"]
             roofline["traffic_source"] = tj.get("source", "profiles/spmv_traffic.json")
 

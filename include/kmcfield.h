@@ -101,6 +101,10 @@ typedef struct {
     int halo_cols;            /* sum over k>=1 of nnz_cols_per_neighbour[k]         */
     int send_rows;            /* sum over k>=1 of nnz_rows_per_neighbour[k]         */
     int boundary_rows;        /* local rows that reference a halo column            */
+    int spmv_kind;            /* 0 vec, 1 stream, 2 window (LDS-staged x window)    */
+    int spmv_coded;           /* 1: values currently dictionary-coded (2 B/nnz)     */
+    int spmv_tiles;           /* window kernel: number of tiles                     */
+    int64_t spmv_window_cols; /* window kernel: sum of the tiles' window sizes      */
 } kmcf_matrix_info_t;
 int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info);
 

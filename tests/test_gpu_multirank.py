@@ -77,7 +77,7 @@ def _run_ranks(km, d, P, ref_charge):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(600)
+        t.join(180)
     assert not errs, "\n".join(errs)
     assert all(o is not None for o in out), "a rank did not finish (deadlock?)"
     for c in comms:

@@ -15,7 +15,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))

@@ -162,6 +162,7 @@ struct kmcf_matrix {
     // products; only the diagonal product is added last instead of in column order.
     bool coded = false;                // codes + d_diagv + d_dict currently match d_val
     bool expect_coded = true;          // plan hint: tiles sized for the coded kernel (<= 8*U rows: full passes)
+    bool tiles_for_coded = false;      // the plan followed the hint (the coded kernel requires its entry limit)
     double *d_dict = nullptr;          // KMCF_DICT_MAX + 1 doubles
     double *d_diagv = nullptr;         // diagonal value per row (0 where a row has no diagonal entry)
     int *d_diag_pos = nullptr;         // nnz index of each row's diagonal entry, -1 if none

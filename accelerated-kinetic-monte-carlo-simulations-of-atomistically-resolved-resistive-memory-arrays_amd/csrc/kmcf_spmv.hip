@@ -202,84 +202,149 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
 // Same tiles, for matrices whose off-diagonal values are all one of <= 62 doubles (K and the CB-edge system:
 // two, -high_G and -low_G): idx16 carries the value's dictionary code above the slot bits and the kernel
 // never reads val -- 2 B/nnz of matrix stream.  Only the 16-bit stream is parked in LDS (not products): the
-// row lanes read slot+code, pick the value (ND <= 2: two registers; else an LDS dictionary), fetch x from the
-// window and accumulate in the same order as the other kernels.  The diagonal entry (code 63, skipped in the
-// stream) comes from diagv and is added after the off-diagonal sum.
-template <int U, int WQ, int ND, bool DOT, bool SKIP_BOUNDARY>
+// row lanes read slot+code, look the value up in an LDS dictionary (entry 63 = 0: the diagonal entry, which
+// is skipped in the stream), fetch x from the window and accumulate in the same order as the other kernels;
+// the diagonal product comes from diagv and is added after the off-diagonal sum.
+//
+// Software-pipelined over the block's tiles: with 2 B/nnz the kernel is no longer bound by HBM but by the
+// latency of one tile's load -> gather -> barrier -> reduce chain at 8 waves per SIMD (measured: loads alone
+// 36 us, reduction alone 28 us, one after the other 58 us).  So the slot stream and window map of tile t+1 are
+// requested before tile t is reduced, and LDS is double-buffered, which also leaves one barrier per tile:
+// buffer b is rewritten for tile t+2 only by threads that passed the barrier of tile t+1, i.e. after every
+// thread finished reducing tile t.
+template <int U>
+struct slot_pack {
+    typedef unsigned int type __attribute__((ext_vector_type(U / 2)));   // U 16-bit entries
+};
+
+template <int U, int WQ>
+__device__ __forceinline__ void wcode_issue_loads(const int *__restrict__ wcol, const unsigned short *__restrict__ idx16,
+                                                  int w0, int W, int base, int tid, int (&wc)[WQ],
+                                                  typename slot_pack<U>::type &pk)
+{
+    // Unconditional loads (lanes past the window end re-read its last element; both arrays are padded): a
+    // branch per load would make the compiler drain every outstanding load at the join (s_waitcnt vmcnt(0))
+    // and with it the prefetch.  The slot stream comes as ONE 2U-byte load per lane: the tile's entries are
+    // read from the last 2U-byte boundary at or below its first entry (a tile of the coded plan holds at most
+    // 256*U - U entries, so the block's 256 lanes still cover it); the reduction adds the offset back.
+    const int wl = W > 0 ? W - 1 : 0;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) wc[q] = __builtin_nontemporal_load(wcol + w0 + min(q * KMCF_BLOCK + tid, wl));
+    const int abase = base & ~(U - 1);
+    pk = __builtin_nontemporal_load(reinterpret_cast<const typename slot_pack<U>::type *>(idx16 + abase) + tid);
+}
+
+template <int U, int WQ, bool DOT, bool SKIP_BOUNDARY>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
     int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
     const unsigned short *__restrict__ idx16, const double *__restrict__ x, double *__restrict__ y,
     const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S,
     int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
 {
-    constexpr int LPR2 = 4, RPP = KMCF_BLOCK / LPR2, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
-    __shared__ double xw[KMCF_BLOCK * WQ];
-    __shared__ unsigned short sidx[KMCF_BLOCK * U];
+    constexpr int LPR2 = 4, RPP = KMCF_BLOCK / LPR2, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1, UN = 4;
+    typedef typename slot_pack<U>::type pack_t;
+    __shared__ double xw[2][KMCF_BLOCK * WQ];
+    __shared__ pack_t sidx_pk[2][KMCF_BLOCK];
+    __shared__ double sdict[64];
     __shared__ double lds4[4];
-    __shared__ double sdict[ND > 2 ? 64 : 1];
     if (check_done && S->done) return;
     const int tid = threadIdx.x;
-    double d0 = 0.0, d1 = 0.0;
-    if (ND <= 2) { d0 = dict[0]; d1 = dict[1]; }
-    else if (tid < 64) sdict[tid] = dict[tid];          // visible after the first tile's barrier
+    if (tid < 64) sdict[tid] = dict[tid];               // visible after the first tile's barrier
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
     const int Cx = (n_tiles + 7) >> 3;  // tiles per XCD
     const int lane = tid % LPR2;
     double dot = 0.0;
-    for (int g = bi; g < Cx; g += nb8) {
-        const int c = xcd * Cx + g;
-        if (c >= n_tiles) break;                       // block-uniform
-        const int2 t0 = tile[c], t1 = tile[c + 1];
-        const int r0 = t0.x, r1 = t1.x, w0 = t0.y, W = t1.y - w0;
-        const int base = row_ptr[r0];
-        const int cnt = row_ptr[r1] - base;
-        int wc[WQ];
+
+    // descriptors and in-flight loads of the tile about to be staged (block-uniform control flow)
+    int g = bi;
+    bool have = g < Cx && xcd * Cx + g < n_tiles;
+    int r0 = 0, r1 = 0, base = 0;
+    int wc[WQ];
+    pack_t pk;
+    // row data of the first pass of that tile (rows past its end re-read its last row): everything the
+    // reduction reads from global memory travels with the prefetch, one tile ahead -- loads return in order,
+    // so a request made after the prefetch would wait behind it
+    int nb = 0, ne = 0;
+    double nxrow = 0.0, ndg = 0.0;
+    if (have) {
+        const int2 t0 = tile[xcd * Cx + g], t1 = tile[xcd * Cx + g + 1];
+        r0 = t0.x; r1 = t1.x;
+        base = row_ptr[r0];
+        wcode_issue_loads<U, WQ>(wcol, idx16, t0.y, t1.y - t0.y, base, tid, wc, pk);
+        const int rc = min(r0 + tid / LPR2, r1 - 1);
+        nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
+    }
+    int buf = 0;
+    while (have) {
+        // entries sit in LDS at their distance from the aligned load start (wcode_issue_loads)
+        const int cr0 = r0, cr1 = r1, cbase = base & ~(U - 1);
+        int rr = cr0 + tid / LPR2;
+        int b = nb - cbase, e = ne - cbase;
+        double xrow = nxrow, dg = ndg;
+        if (rr >= cr1) b = e = 0;
+        double xr[WQ];
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int w = q * KMCF_BLOCK + tid;
-            wc[q] = w < W ? __builtin_nontemporal_load(wcol + w0 + w) : -1;
+        for (int q = 0; q < WQ; ++q) xr[q] = x[wc[q]];
+        sidx_pk[buf][tid] = pk;
+        // prefetch: slot stream, window map and row data of the block's next tile (the current one again at
+        // the end: no branch around the loads, see wcode_issue_loads)
+        const int gn = g + nb8;
+        const bool have_n = gn < Cx && xcd * Cx + gn < n_tiles;
+        {
+            const int cn = xcd * Cx + (have_n ? gn : g);
+            const int2 t0 = tile[cn], t1 = tile[cn + 1];
+            r0 = t0.x; r1 = t1.x;
+            base = row_ptr[r0];
+            wcode_issue_loads<U, WQ>(wcol, idx16, t0.y, t1.y - t0.y, base, tid, wc, pk);
+            const int rc = min(r0 + tid / LPR2, r1 - 1);
+            nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
         }
-        unsigned short ci[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = u * KMCF_BLOCK + tid;
-            ci[u] = i < cnt ? __builtin_nontemporal_load(idx16 + base + i) : (unsigned short)0;
-        }
-        // row bounds of the first pass while the loads are in flight
-        int rr = r0 + tid / LPR2;
-        int b = 0, e = 0;
-        if (rr < r1) { b = row_ptr[rr] - base; e = row_ptr[rr + 1] - base; }
-#pragma unroll
-        for (int q = 0; q < WQ; ++q)
-            if (wc[q] >= 0) xw[q * KMCF_BLOCK + tid] = x[wc[q]];
-#pragma unroll
-        for (int u = 0; u < U; ++u) sidx[u * KMCF_BLOCK + tid] = ci[u];
+        for (int q = 0; q < WQ; ++q) xw[buf][q * KMCF_BLOCK + tid] = xr[q];
         __syncthreads();
-        const int passes = (r1 - r0 + RPP - 1) / RPP;
+        const double *xwb = xw[buf];
+        const unsigned short *sib = reinterpret_cast<const unsigned short *>(sidx_pk[buf]);
+        const int passes = (cr1 - cr0 + RPP - 1) / RPP;
         for (int ps = 0; ps < passes; ++ps) {
-            if (ps > 0) {
-                rr = r0 + ps * RPP + tid / LPR2;
-                b = e = 0;
-                if (rr < r1) { b = row_ptr[rr] - base; e = row_ptr[rr + 1] - base; }
+            if (ps > 0) {                                  // tiles of the coded plan hold <= RPP rows per U = 8
+                rr = cr0 + ps * RPP + tid / LPR2;
+                const int rc = min(rr, cr1 - 1);
+                b = row_ptr[rc] - cbase;
+                e = row_ptr[rc + 1] - cbase;
+                xrow = x[rc];
+                dg = diagv[rc];
+                if (rr >= cr1) b = e = 0;
             }
-            const bool valid = rr < r1;
+            const bool valid = rr < cr1;
             double s = 0.0;
-            for (int j = b + lane; j < e; j += LPR2) {
-                const int cc = sidx[j];
-                const int code = cc >> KMCF_SLOT_BITS;
-                const double xv = xw[cc & SLOT_MASK];
-                const double v = ND <= 2 ? (code == 0 ? d0 : d1) : sdict[code];
-                s += code == KMCF_CODE_DIAG ? 0.0 : v * xv;
+            // UN entries per step with independent LDS reads; entries past the row end read as the diagonal
+            // code, whose dictionary value is 0.  The adds stay in entry order: same sums as the other kernels.
+            for (int j0 = b + lane; j0 < e; j0 += LPR2 * UN) {
+                int cc[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const int j = j0 + LPR2 * k;
+                    cc[k] = j < e ? (int)sib[j] : (KMCF_CODE_DIAG << KMCF_SLOT_BITS);
+                }
+                double xv[UN], vv[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    xv[k] = xwb[cc[k] & SLOT_MASK];
+                    vv[k] = sdict[cc[k] >> KMCF_SLOT_BITS];
+                }
+#pragma unroll
+                for (int k = 0; k < UN; ++k) s += vv[k] * xv[k];
             }
             s = wave_sum_width(s, LPR2);
             if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
-                const double xr = x[rr];
-                s += diagv[rr] * xr;
+                s += dg * xrow;
                 y[rr] = s;
-                if (DOT) dot += xr * s;
+                if (DOT) dot += xrow * s;
             }
         }
-        __syncthreads();
+        g = gn;
+        have = have_n;
+        buf ^= 1;
     }
     if (DOT) {
         double t = block_sum_256(dot, lds4);
@@ -442,9 +507,8 @@ void run_or_query(K kernel, bool launch, int *per_cu, int grid, hipStream_t st, 
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, KMCF_BLOCK, 0) != hipSuccess) *per_cu = 0;
 }
 
-// One place that names every window-kernel instance.  which: 0 plain (values streamed), 1 coded with <= 2
-// dictionary values, 2 coded with an LDS dictionary.  launch = false: return the resident blocks per CU of
-// that instance instead of launching it.
+// One place that names every window-kernel instance.  which: 0 plain (values streamed), 1 dictionary-coded.
+// launch = false: return the resident blocks per CU of that instance instead of launching it.
 template <int U, int WQ>
 int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool skip_if_done)
 {
@@ -463,21 +527,13 @@ int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool 
             if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, false, true>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
             else run_or_query(spmv_window_kernel<U, WQ, 4, false, false>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
         }
-    } else if (which == 1) {
-        if (with_dot) {
-            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 2, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-            else run_or_query(spmv_wcode_kernel<U, WQ, 2, true, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-        } else {
-            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 2, false, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-            else run_or_query(spmv_wcode_kernel<U, WQ, 2, false, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-        }
     } else {
         if (with_dot) {
-            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 64, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-            else run_or_query(spmv_wcode_kernel<U, WQ, 64, true, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, true, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
         } else {
-            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, 64, false, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
-            else run_or_query(spmv_wcode_kernel<U, WQ, 64, false, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, false, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
+            else run_or_query(spmv_wcode_kernel<U, WQ, false, false>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
         }
     }
     return pc;
@@ -513,7 +569,7 @@ int window_grid(kmcf_matrix *m, int which)
 void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     if (m->spmv_kind == 2) {
-        window_dispatch_any(m, m->coded ? (m->dict_n <= 2 ? 1 : 2) : 0, true, with_dot, skip_if_done);
+        window_dispatch_any(m, m->coded ? 1 : 0, true, with_dot, skip_if_done);
     } else if (m->spmv_kind == 1) {
         const int key = m->spmv_u * 100 + m->spmv_lpr2;
         switch (key) {
@@ -551,7 +607,9 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     // the value stream, prefers tiles filled to the entry limit
     const char *ce = getenv("KMCF_SPMV_CODED");
     const bool for_coded = m->expect_coded && !(ce && atoi(ce) == 0);
-    const int cap = KMCF_BLOCK * u, wmax = KMCF_BLOCK * wq, row_cap = for_coded ? 8 * u : n;
+    // (the coded kernel reads a tile's slot stream from an aligned start up to u - 1 entries early: spmv_wcode_kernel)
+    const int cap = KMCF_BLOCK * u - (for_coded ? u : 0), wmax = KMCF_BLOCK * wq, row_cap = for_coded ? 8 * u : n;
+    m->tiles_for_coded = for_coded;
     std::vector<int> col((size_t)m->nnz);
     KMCF_HIP(hipMemcpy(col.data(), m->d_col, col.size() * sizeof(int), hipMemcpyDeviceToHost));
     std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1);
@@ -589,13 +647,15 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
         fprintf(stderr, "kmcf window plan: %d tiles, %.1f rows, %.1f nnz, %.1f window columns per tile\n", nt, double(n) / nt,
                 double(m->nnz) / nt, double(wcol.size()) / nt);
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tile), tiles.size() * sizeof(int2)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_wcol), std::max<size_t>(wcol.size(), 1) * sizeof(int)));
+    wcol.push_back(0);                                    // spare elements: wcode_issue_loads clamps, never branches
+    idx.resize(idx.size() + KMCF_BLOCK * 16 + 16, 0);    // the coded kernel's block-wide slot load may run past the last tile
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_wcol), wcol.size() * sizeof(int)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_idx16), idx.size() * sizeof(unsigned short)));
     KMCF_HIP(hipMemcpy(m->d_tile, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(m->d_wcol, wcol.data(), wcol.size() * sizeof(int), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(m->d_idx16, idx.data(), idx.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     m->n_tiles = nt;
-    m->n_wcols = (int64_t)wcol.size();
+    m->n_wcols = (int64_t)wcol.size() - 1;              // without the spare element
     m->spmv_wmax = wmax;
     // diagonal positions and the buffers of the dictionary-coded variant (codes are written later, by
     // kmcf_matrix_encode_values or by the K assembly)
@@ -671,8 +731,8 @@ int kmcf_spmv_plan(kmcf_matrix *m)
     const bool judge = kind < 0;
     if (kind < 0 || kind > 2) kind = 2;
     if (kind == 2) {
-        int wq = env_int("KMCF_SPMV_WQ", 3);
-        if (wq != 2 && wq != 3 && wq != 4) wq = 3;
+        int wq = env_int("KMCF_SPMV_WQ", 2);             // 512 window columns: K tiles need ~300 (measured best)
+        if (wq != 2 && wq != 3 && wq != 4) wq = 2;
         // instantiated (U, WQ) pairs: window_dispatch_any
         const int uw = (u == 4 && wq == 2) ? 4 : ((u == 16 && wq >= 3) ? 16 : 8);
         bool ok = false;
@@ -715,7 +775,7 @@ int kmcf_spmv_plan(kmcf_matrix *m)
 
 static bool coding_enabled(const kmcf_matrix *m)
 {
-    if (m->spmv_kind != 2 || !m->d_idx16) return false;
+    if (m->spmv_kind != 2 || !m->d_idx16 || !m->tiles_for_coded) return false;
     const char *e = getenv("KMCF_SPMV_CODED");
     return !(e && atoi(e) == 0);
 }
@@ -734,9 +794,7 @@ int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
         KMCF_HIP(hipMemcpyAsync(m->d_dict, m->h_dict, sizeof(m->h_dict), hipMemcpyHostToDevice, m->comm->stream));
         m->dict_uploaded = true;
     }
-    const int which = nd <= 2 ? 1 : 2;
-    if (m->dict_n != nd || m->spmv_grid_coded <= 0 || (m->dict_n <= 2 ? 1 : 2) != which)
-        m->spmv_grid_coded = window_grid(m, which);
+    if (m->spmv_grid_coded <= 0) m->spmv_grid_coded = window_grid(m, 1);
     m->dict_n = nd;
     m->coded = true;
     return KMCF_OK;

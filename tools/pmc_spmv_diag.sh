@@ -16,13 +16,10 @@ while read -r group; do
   timeout -k 5 150 rocprofv3 --kernel-trace --pmc $group -d $R/gpurun_out/pmcdiag/g$i -o x --output-format csv -- \
       python3 $R/tools/spmv_lab.py "$SPEC" > $R/gpurun_out/pmcdiag/g$i.log 2>&1 || echo "pass $i failed"
 done <<EOF
-TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum
-TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
-TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum
-TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum
-TCP_GATE_EN1_sum TCP_GATE_EN2_sum
-TCC_HIT_sum TCC_MISS_sum
-TCC_REQ_sum TCC_READ_sum
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
+SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
+TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum
+TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
 EOF
 python3 - <<PY
 import csv, glob, collections

@@ -118,15 +118,30 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
         else S->done = 1;
     }
     if (!go) return;
+    // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned)
+    const int n2 = n >> 1;
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *d2 = reinterpret_cast<const double2 *>(dinv);
+    double2 *p2 = reinterpret_cast<double2 *>(p);
     if (first) {
-        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK)
-            p[i] = PRECOND ? r[i] * dinv[i] : r[i];                       // :226 dcopy(z -> p)
+        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
+            double2 rv = r2[i];
+            if (PRECOND) { const double2 dv = d2[i]; rv.x *= dv.x; rv.y *= dv.y; }
+            p2[i] = rv;                                                    // :226 dcopy(z -> p)
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = PRECOND ? r[n - 1] * dinv[n - 1] : r[n - 1];
     } else {
         const double beta = rz_new / S->rz[parity ^ 1];                    // :220
-        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
-            double z = PRECOND ? r[i] * dinv[i] : r[i];
-            double bp = beta * p[i];                                       // :221 dscal
-            p[i] = bp + z;                                                 // :222 daxpy
+        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
+            double2 z = r2[i];
+            if (PRECOND) { const double2 dv = d2[i]; z.x *= dv.x; z.y *= dv.y; }
+            double2 pv = p2[i];
+            pv.x = beta * pv.x + z.x;                                      // :221 dscal, :222 daxpy
+            pv.y = beta * pv.y + z.y;
+            p2[i] = pv;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const double z = PRECOND ? r[n - 1] * dinv[n - 1] : r[n - 1];
+            p[n - 1] = beta * p[n - 1] + z;
         }
     }
 }
@@ -145,11 +160,32 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
     const double a = S->rz[parity] / pAp;
     const double na = -a;
     double rz = 0.0;
-    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
+    // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned)
+    const int n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap),
+                  *d2 = reinterpret_cast<const double2 *>(dinv);
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
+        double2 xv = x2[i];
+        const double2 pv = p2[i], av = A2[i];
+        double2 rv = r2[i];
+        xv.x = xv.x + a * pv.x;
+        xv.y = xv.y + a * pv.y;
+        x2[i] = xv;
+        rv.x = rv.x + na * av.x;
+        rv.y = rv.y + na * av.y;
+        r2[i] = rv;
+        double2 z = rv;
+        if (PRECOND) { const double2 dv = d2[i]; z.x *= dv.x; z.y *= dv.y; }
+        rz += rv.x * z.x;
+        rz += rv.y * z.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int i = n - 1;
         x[i] = x[i] + a * p[i];
-        double ri = r[i] + na * Ap[i];
+        const double ri = r[i] + na * Ap[i];
         r[i] = ri;
-        double z = PRECOND ? ri * dinv[i] : ri;
+        const double z = PRECOND ? ri * dinv[i] : ri;
         rz += ri * z;
     }
     double t = block_sum(rz, lds4);
@@ -172,7 +208,7 @@ int vec_grid(int n)
 {
     int64_t g = ((int64_t)n + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
     if (g < 1) g = 1;
-    if (g > 1024) g = 1024;
+    if (g > KMCF_MAX_PARTIALS) g = KMCF_MAX_PARTIALS;    // 8 blocks per CU; one partial per block
     return (int)g;
 }
 

@@ -1,13 +1,16 @@
 // CSR SpMV for gfx950 (wave64), replacing rocsparse_spmv csr_adaptive/csr_stream
 // (dist_iterative/dist_spmv_gpu_packing.cpp:161-194).
 //
-// HBM-bound: per launch the kernel streams 12 B/nnz (f64 value + i32 column) +
-// 20 B/row (row_ptr, x once, y once); x gathers are served by L2/Infinity Cache.
-// No MFMA: 2 flop per 12 streamed bytes.
+// HBM-bound work: a CSR launch streams 12 B/nnz (f64 value + i32 column) + 20 B/row (row_ptr, x once,
+// y once); x gathers are served by L2/Infinity Cache.  No MFMA: 2 flop per 12 streamed bytes.
 //
-// Two kernels, chosen per matrix in kmcf_spmv_plan():
+// Four kernels, chosen per matrix in kmcf_spmv_plan() (DESIGN.md 3.1 has the measurements behind each):
 //
-//  "stream" (default for short rows, e.g. K: 4..53 nnz/row): the nnz range is cut
+//  "window" / "window, coded" (default where columns are local, e.g. K in its internal brick order):
+//    tiles of whole rows whose distinct columns are staged once in LDS; entries carry a 16-bit window
+//    slot instead of a column, and -- where the off-diagonal values come from a small dictionary, as K's
+//    two conductances do -- a 6-bit value code instead of an f64 value: 2 B/nnz.  See the kernels below.
+//  "stream" (short rows with scattered columns): the nnz range is cut
 //    into chunks of whole rows (<= 256*U nnz).  A 256-thread block streams a chunk's
 //    values and columns with fully coalesced loads that do not depend on row_ptr (U
 //    independent loads per lane in flight -> memory-level parallelism instead of the
@@ -17,7 +20,7 @@
 //    reduction.  Used for the boundary-row pass (row list) and for matrices with rows
 //    longer than a chunk.
 //
-// Both fuse the p.Ap dot product of CG (one partial per block, reduced in a fixed order
+// All fuse the p.Ap dot product of CG (one partial per block, reduced in a fixed order
 // by the consumer kernel) and map blocks to rows XCD-aware: blocks with equal
 // blockIdx % 8 (same XCD, same L2) walk one contiguous eighth of the matrix, so each L2
 // holds one window of x.
@@ -65,12 +68,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
     const int Cx = (n_chunks + 7) >> 3;  // chunks per XCD
     double dot = 0.0;
-    for (int g0 = bi; g0 < Cx + nb8; g0 += nb8) {
-        // check_done bit 1 (lab): co-resident blocks of a CU (assumed bi % 32 == CU) take adjacent chunks
-        int g = g0;
-        if ((check_done & 2) && nb8 == 256) g = (g0 & ~255) + ((bi & 31) << 3) + (bi >> 5);
+    for (int g = bi; g < Cx; g += nb8) {
         const int c = xcd * Cx + g;
-        if (g >= Cx || c >= n_chunks) { if (check_done & 2) continue; else break; }   // block-uniform
+        if (c >= n_chunks) break;                      // block-uniform
         const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
         const int base = row_ptr[r0];
         const int cnt = row_ptr[r1] - base;
@@ -483,7 +483,7 @@ template <int U, int LPR2>
 void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     hipStream_t st = m->comm->stream;
-    const int chk = (skip_if_done ? 1 : 0) | (getenv("KMCF_SPMV_MAP") ? 2 : 0);
+    const int chk = skip_if_done ? 1 : 0;
     const int grid = kmcf_interior_grid(m);
     const bool skipb = (m->n_halo > 0);
     if (with_dot) {

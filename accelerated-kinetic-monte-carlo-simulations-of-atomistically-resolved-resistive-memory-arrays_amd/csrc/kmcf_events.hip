@@ -6,15 +6,17 @@
 // a device upper_bound, a full zero-out pass, three host syncs.  Here the list keeps a two-level sum tree
 // (one sum per 2048-slot tile, one per group of 256 tiles), no scan array at all:
 //   per step : build kernel (type u8 + probability f64 per slot), tile sums, symmetry check of the lists
-//   per event: group sums + total (one small kernel) -> select: walk <= G groups, <= 256 tiles, <= 2048
-//              slots -> execute -> zero the events touching the pair and refresh the affected tile sums.
-//              One rank with symmetric neighbour lists: only the rows of i, j and of their listed
-//              neighbours are visited (<= 2 + 2 nn rows, <= 4 nn + 4 tiles) and the whole event needs ONE
-//              host sync; otherwise a full pass over this rank's slots (the reference's way).
+//   per event: select = three block-wide searches (group sums, the <= 256 tile sums of one group, the <= 2048
+//              slots of one tile) -> execute -> zero the events touching the pair and refresh the affected
+//              tile and group sums.  One rank with symmetric neighbour lists: only the rows of i, j and of
+//              their listed neighbours are visited (<= 2 + 2 nn rows, <= 4 nn + 4 tiles), select + execute +
+//              zero-out are one launch, and the whole event needs ONE host sync; otherwise a full pass over
+//              this rank's slots (the reference's way).
 // Same selection rule (first slot whose inclusive cumulative sum exceeds u * total), same event rules,
 // same loop (events are drawn until the LAST drawn residence time reaches 1/freq; that last draw is the
 // returned time).  Ranks own contiguous site ranges; the partial totals are all-gathered and the rank
 // whose range holds the drawn number selects (MPI_Allgather + MPI_Bcast in the reference, :423-470).
+#include <climits>
 #include <cmath>
 #include <random>
 #include <vector>
@@ -149,36 +151,6 @@ __global__ __launch_bounds__(KMCF_BLOCK) void zero_and_sum_kernel(size_t M, int 
     if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
 }
 
-// Neighbour-list shortcut of the zero-out (one rank, symmetric lists): rows i_del and j_del lose all their
-// events; a row n that lists i_del or j_del is, by symmetry, listed by them.  One block; the affected
-// tile ids go to aff[0 .. 4 nn + 4) (-1 = none; duplicates are harmless).
-__global__ void zero_rows_kernel(int nn, const int *__restrict__ neigh_idx, unsigned char *__restrict__ event_type,
-                                 double *__restrict__ event_prob, const int *__restrict__ ijevent, int *__restrict__ aff)
-{
-    const int i_del = ijevent[0], j_del = ijevent[1];
-    for (int t = threadIdx.x; t < 2 * nn; t += blockDim.x) {
-        const int s = t < nn ? i_del : j_del;
-        const size_t own = (size_t)s * nn + (t % nn);
-        if (neigh_idx[own] >= 0) { event_type[own] = (unsigned char)EV_NULL; event_prob[own] = 0.0; }
-        const int n = neigh_idx[own];
-        aff[2 * t] = aff[2 * t + 1] = -1;
-        if (n >= 0) {
-            const size_t rb = (size_t)n * nn;
-            for (int q = 0; q < nn; ++q) {
-                const int jj = neigh_idx[rb + q];
-                if (jj == i_del || jj == j_del) { event_type[rb + q] = (unsigned char)EV_NULL; event_prob[rb + q] = 0.0; }
-            }
-            aff[2 * t] = (int)(rb / EV_TILE);
-            aff[2 * t + 1] = (int)((rb + nn - 1) / EV_TILE);
-        }
-    }
-    if (threadIdx.x < 2) {
-        const size_t rb = (size_t)(threadIdx.x == 0 ? i_del : j_del) * nn;
-        aff[4 * nn + 2 * threadIdx.x] = (int)(rb / EV_TILE);
-        aff[4 * nn + 2 * threadIdx.x + 1] = (int)((rb + nn - 1) / EV_TILE);
-    }
-}
-
 // refresh the tile sums listed in aff (one block per entry)
 __global__ __launch_bounds__(KMCF_BLOCK) void tile_sum_kernel(size_t M, const double *__restrict__ event_prob,
                                                               const int *__restrict__ aff, double *__restrict__ tsum)
@@ -217,35 +189,168 @@ __global__ void total_kernel(int ng, const double *__restrict__ gsum, double *__
     *total = s;
 }
 
-// First slot whose inclusive cumulative sum exceeds the drawn number (thrust::upper_bound on the scan,
-// :444): walk the groups, then the tiles of one group, then the slots of one tile.  number < 0: the
-// number is u * total with u given (single-rank path: one host sync per event); out[3..4] = total bits.
-__global__ void select_event_kernel(size_t M, int nb, int ng, int start_i, int nn, double number, double u,
-                                    const double *__restrict__ gsum, const double *__restrict__ tsum,
-                                    const double *__restrict__ event_prob, const unsigned char *__restrict__ event_type,
-                                    const int *__restrict__ neigh_idx, int *__restrict__ ijevent, double *__restrict__ total_out)
+// refresh the sums of the groups that hold a tile listed in aff (one thread per entry; duplicates rewrite
+// the same value)
+__global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(int n_aff, const int *__restrict__ aff, int nb,
+                                                                   const double *__restrict__ tsum, double *__restrict__ gsum)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_aff) return;
+    const int tile = aff[t];
+    if (tile < 0) return;
+    const int g = tile / EV_GROUP;
+    const int b0 = g * EV_GROUP, b1 = min(b0 + EV_GROUP, nb);
+    double s = 0.0;
+    for (int b = b0; b < b1; ++b) s += tsum[b];
+    gsum[g] = s;
+}
+
+struct search_lds {
+    double wave_tot[4];
+    double acc_found, acc_last;
+    int found, last;
+};
+
+// Block-wide (256 threads) search for the first index k in [0, L) with  acc + (a[0] + ... + a[k]) > number.
+// A thread owns 8 consecutive entries: running sums inside the thread, a block scan of the thread totals on
+// top, so every cumulative sum is formed in one fixed order.  (It is not the order of a one-thread walk: the
+// two can pick different slots only when `number` lies within rounding of a slot boundary.)  If the sums
+// never exceed `number` -- rounding at the very end of the list -- the last entry with a positive value is
+// taken.  Returns the index, or -1 if no entry is positive; *acc becomes the cumulative sum before it.
+__device__ int block_search_256(const double *__restrict__ a, int L, double number, double *acc, search_lds *sh)
+{
+    constexpr int PER = 8, SEG = KMCF_BLOCK * PER;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double base = *acc;
+    if (tid == 0) { sh->found = INT_MAX; sh->last = -1; }
+    __syncthreads();
+    for (int s0 = 0; s0 < L; s0 += SEG) {
+        double p[PER];
+        double run = 0.0;
+        int my_last = -1;
+        double my_last_acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = s0 + tid * PER + k;
+            const double v = idx < L ? a[idx] : 0.0;
+            if (v > 0.0) { my_last = idx; my_last_acc = run; }
+            run += v;
+            p[k] = run;
+        }
+        double incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0.0;
+        if (lane == 63) sh->wave_tot[w] = incl;
+        __syncthreads();
+        double wave_off = 0.0;
+        for (int q = 0; q < w; ++q) wave_off += sh->wave_tot[q];
+        const double seg_total = ((sh->wave_tot[0] + sh->wave_tot[1]) + sh->wave_tot[2]) + sh->wave_tot[3];
+        const double mine = base + wave_off + excl;          // cumulative sum before this thread's entries
+        int cand = INT_MAX;
+        double cand_acc = 0.0;
+#pragma unroll
+        for (int k = PER - 1; k >= 0; --k) {
+            const int idx = s0 + tid * PER + k;
+            if (idx < L && mine + p[k] > number) { cand = idx; cand_acc = mine + (k ? p[k - 1] : 0.0); }
+        }
+        if (cand != INT_MAX) atomicMin(&sh->found, cand);
+        if (my_last >= 0) atomicMax(&sh->last, my_last);
+        __syncthreads();
+        if (cand != INT_MAX && sh->found == cand) sh->acc_found = cand_acc;
+        if (my_last >= 0 && sh->last == my_last) sh->acc_last = mine + my_last_acc;
+        __syncthreads();
+        if (sh->found != INT_MAX) break;                      // block-uniform
+        base += seg_total;
+    }
+    int r = sh->found;
+    if (r != INT_MAX) *acc = sh->acc_found;
+    else { r = sh->last; if (r >= 0) *acc = sh->acc_last; }
+    __syncthreads();                                          // sh is reused by the next search
+    return r;
+}
+
+// First slot whose inclusive cumulative sum exceeds the drawn number (thrust::upper_bound on the scan,
+// :444): search the group sums, then the tile sums of that group, then the slots of that tile -- three
+// block-wide searches of one 256-thread block.  number < 0: the number is u * total with u given and the
+// total is formed here (single-rank path: one host sync per event).  FUSED: thread 0 then executes the event
+// (execute_event, :284-331) and the block zeroes the events of the pair through the neighbour lists
+// (zero_rows_kernel) -- one launch instead of three.
+template <bool FUSED>
+__global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
+    size_t M, int nb, int ng, int start_i, int nn, double number, double u, const double *__restrict__ gsum,
+    const double *__restrict__ tsum, double *__restrict__ event_prob, unsigned char *__restrict__ event_type,
+    const int *__restrict__ neigh_idx, int *__restrict__ ijevent, double *__restrict__ total_out,
+    int *__restrict__ site_element, int *__restrict__ site_charge, int *__restrict__ aff)
+{
+    __shared__ search_lds sh;
+    __shared__ double lds4[4];
+    __shared__ int s_ij[3];
     if (number < 0) {
-        double total = 0.0;
-        for (int g = 0; g < ng; ++g) total += gsum[g];
-        *total_out = total;
+        double s = 0.0;
+        for (int g = threadIdx.x; g < ng; g += KMCF_BLOCK) s += gsum[g];
+        const double total = block_sum_ev(s, lds4);
+        if (threadIdx.x == 0) *total_out = total;
         number = u * total;
     }
     double acc = 0.0;
-    int g = 0;
-    while (g + 1 < ng && !(number < acc + gsum[g])) { acc += gsum[g]; ++g; }
-    int b = g * EV_GROUP;
-    const int b_end = min(b + EV_GROUP, nb);
-    while (b + 1 < b_end && !(number < acc + tsum[b])) { acc += tsum[b]; ++b; }
-    size_t id = (size_t)b * EV_TILE;
-    const size_t e = id + EV_TILE < M ? id + EV_TILE : M;
-    double c = acc;
-    for (; id < e; ++id) { c += event_prob[id]; if (number < c) break; }
-    if (id >= M) id = M - 1;
-    ijevent[0] = (int)(id / nn) + start_i;
-    ijevent[1] = neigh_idx[id];
-    ijevent[2] = (int)event_type[id];
+    int g = block_search_256(gsum, ng, number, &acc, &sh);
+    if (g < 0) g = 0;
+    const int b0 = g * EV_GROUP;
+    int b = block_search_256(tsum + b0, min(EV_GROUP, nb - b0), number, &acc, &sh);
+    b = b0 + (b < 0 ? 0 : b);
+    const size_t id0 = (size_t)b * EV_TILE;
+    const int L = (int)(id0 + EV_TILE < M ? (size_t)EV_TILE : M - id0);
+    int k = block_search_256(event_prob + id0, L, number, &acc, &sh);
+    if (k < 0) k = 0;
+    const size_t id = id0 + k;
+    if (threadIdx.x == 0) {
+        const int i = (int)(id / nn) + start_i, j = neigh_idx[id], et = (int)event_type[id];
+        ijevent[0] = s_ij[0] = i;
+        ijevent[1] = s_ij[1] = j;
+        ijevent[2] = s_ij[2] = et;
+        if (FUSED && j >= 0) {
+            if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
+            else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
+            else if (et == EV_VDIFF || et == EV_ODIFF) {
+                const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
+                const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+            }
+        }
+    }
+    if (!FUSED) return;
+    __syncthreads();
+    const int i_del = s_ij[0], j_del = s_ij[1];
+    for (int t = threadIdx.x; t < 4 * nn + 4; t += KMCF_BLOCK) aff[t] = -1;
+    if (j_del < 0) return;                                     // nothing selectable: the host reports it
+    __syncthreads();
+    // rows i_del and j_del lose all their events; a row n that lists i_del or j_del is, by symmetry, listed
+    // by them (one rank, symmetric lists).  Affected tile ids -> aff (duplicates are harmless).
+    for (int t = threadIdx.x; t < 2 * nn; t += KMCF_BLOCK) {
+        const int s = t < nn ? i_del : j_del;
+        const size_t own = (size_t)s * nn + (t % nn);
+        const int n = neigh_idx[own];
+        if (n >= 0) {
+            event_type[own] = (unsigned char)EV_NULL;
+            event_prob[own] = 0.0;
+            const size_t rb = (size_t)n * nn;
+            for (int q = 0; q < nn; ++q) {
+                const int jj = neigh_idx[rb + q];
+                if (jj == i_del || jj == j_del) { event_type[rb + q] = (unsigned char)EV_NULL; event_prob[rb + q] = 0.0; }
+            }
+            aff[2 * t] = (int)(rb / EV_TILE);
+            aff[2 * t + 1] = (int)((rb + nn - 1) / EV_TILE);
+        }
+    }
+    if (threadIdx.x < 2) {
+        const size_t rb = (size_t)(threadIdx.x == 0 ? i_del : j_del) * nn;
+        aff[4 * nn + 2 * threadIdx.x] = (int)(rb / EV_TILE);
+        aff[4 * nn + 2 * threadIdx.x + 1] = (int)((rb + nn - 1) / EV_TILE);
+    }
 }
 
 // execute_event, :284-331
@@ -341,18 +446,20 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
     int nev = 0;
     std::vector<double> totals(P);
     const int ggrid = (ng + KMCF_BLOCK - 1) / KMCF_BLOCK;
+    // fast path: all group sums once, afterwards only the groups of the tiles an event touched
+    if (fast && M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
     while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                          // :418
-        if (M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
+        if (!fast && M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
         double total = 0.0;
         int ij[3];
         int source_rank = 0;
         if (fast) {
             const double u = next_random(rng_user);                                       // :430
-            select_event_kernel<<<1, 64, 0, st>>>(M, nb, ng, start_i, nn, -1.0, u, d_gsum, d_tsum, d_prob, d_type, d_neigh_idx,
-                                                  d_ij, d_tot);
-            execute_event_kernel<<<1, 64, 0, st>>>(d_site_element, d_site_charge, d_ij);
-            zero_rows_kernel<<<1, 128, 0, st>>>(nn, d_neigh_idx, d_type, d_prob, d_ij, d_aff);
+            // three launches per event: select + execute + zero-out, tile sums, group sums
+            select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, u, d_gsum, d_tsum, d_prob, d_type,
+                                                                d_neigh_idx, d_ij, d_tot, d_site_element, d_site_charge, d_aff);
             tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
+            group_sum_aff_kernel<<<(n_aff + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(n_aff, d_aff, nb, d_tsum, d_gsum);
             if (hipMemcpyAsync(ij, d_ij, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(&total, d_tot, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
@@ -371,8 +478,9 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
             if (rank == source_rank && M > 0) {
                 if (rank > 0) number -= totals[rank - 1];                                 // :440-442
                 if (number < 0) number = 0;
-                select_event_kernel<<<1, 64, 0, st>>>(M, nb, ng, start_i, nn, number, 0.0, d_gsum, d_tsum, d_prob, d_type,
-                                                      d_neigh_idx, d_ij + 3 * rank, d_tot + rank);
+                select_event_kernel<false><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, number, 0.0, d_gsum, d_tsum, d_prob,
+                                                                     d_type, d_neigh_idx, d_ij + 3 * rank, d_tot + rank,
+                                                                     nullptr, nullptr, nullptr);
             }
             if (kmcf_comm_allgatherv_int(c, d_ij, threes.data(), iota3.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }  // MPI_Bcast :455-459
             if (hipMemcpyAsync(ij, d_ij + 3 * source_rank, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -280,20 +280,38 @@ __device__ int block_search_256(const double *__restrict__ a, int L, double numb
 // total is formed here (single-rank path: one host sync per event).  FUSED: thread 0 then executes the event
 // (execute_event, :284-331) and the block zeroes the events of the pair through the neighbour lists
 // (zero_rows_kernel) -- one launch instead of three.
+//
+// FUSED launches come in batches without a host round trip in between (the host pre-draws the random numbers):
+// event `ev` of the batch takes its two uniforms from batch_u[2 ev], [2 ev + 1], logs (i, j, type) and the
+// total, and decides itself whether the step goes on (residence time -log(u2)/total < 1/freq, :418, :479);
+// once the step has ended the remaining launches of the batch return at once.
+struct event_batch_state {
+    int done;      // 0 running, 1 the last executed event ended the step, 2 no event could be selected
+    int n_exec;    // events executed in this batch
+};
+
 template <bool FUSED>
 __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
     size_t M, int nb, int ng, int start_i, int nn, double number, double u, const double *__restrict__ gsum,
     const double *__restrict__ tsum, double *__restrict__ event_prob, unsigned char *__restrict__ event_type,
     const int *__restrict__ neigh_idx, int *__restrict__ ijevent, double *__restrict__ total_out,
-    int *__restrict__ site_element, int *__restrict__ site_charge, int *__restrict__ aff)
+    int *__restrict__ site_element, int *__restrict__ site_charge, int *__restrict__ aff, int ev,
+    const double *__restrict__ batch_u, event_batch_state *__restrict__ state, double inv_freq)
 {
     __shared__ search_lds sh;
     __shared__ double lds4[4];
     __shared__ int s_ij[3];
+    double total = 0.0;
+    if (FUSED) {
+        if (state->done) return;                               // block-uniform
+        u = batch_u[2 * ev];
+        ijevent += 3 * ev;
+        total_out += ev;
+    }
     if (number < 0) {
         double s = 0.0;
         for (int g = threadIdx.x; g < ng; g += KMCF_BLOCK) s += gsum[g];
-        const double total = block_sum_ev(s, lds4);
+        total = block_sum_ev(s, lds4);
         if (threadIdx.x == 0) *total_out = total;
         number = u * total;
     }
@@ -321,12 +339,21 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
                 const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
             }
         }
+        if (FUSED) {
+            if (j < 0) {
+                state->done = 2;                               // nothing selectable: the host reports it
+            } else {
+                state->n_exec = ev + 1;
+                const double t_res = -log(batch_u[2 * ev + 1]) / total;
+                if (!(t_res < inv_freq)) state->done = 1;      // this event was the step's last
+            }
+        }
     }
     if (!FUSED) return;
     __syncthreads();
     const int i_del = s_ij[0], j_del = s_ij[1];
     for (int t = threadIdx.x; t < 4 * nn + 4; t += KMCF_BLOCK) aff[t] = -1;
-    if (j_del < 0) return;                                     // nothing selectable: the host reports it
+    if (j_del < 0) return;
     __syncthreads();
     // rows i_del and j_del lose all their events; a row n that lists i_del or j_del is, by symmetry, listed
     // by them (one rank, symmetric lists).  Affected tile ids -> aff (duplicates are harmless).
@@ -446,24 +473,77 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
     int nev = 0;
     std::vector<double> totals(P);
     const int ggrid = (ng + KMCF_BLOCK - 1) / KMCF_BLOCK;
-    // fast path: all group sums once, afterwards only the groups of the tiles an event touched
-    if (fast && M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
-    while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                          // :418
-        if (!fast && M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
+    if (fast && M > 0 && rc == KMCF_OK) {
+        // Fast path.  All group sums once, afterwards only the groups of the tiles an event touched; three
+        // launches per event (select + execute + zero-out, tile sums, group sums); events are enqueued in
+        // batches with ONE host round trip per batch: the two uniforms of every event of the batch are drawn
+        // ahead, the device decides after each event whether the step goes on, and the launches behind the
+        // step's last event return at once.  With the library's own generator the draws are made on a copy of
+        // its state and the real generator is advanced by what was consumed, so the caller's stream is used
+        // exactly as by the reference (two draws per executed event); a foreign callback cannot be rewound,
+        // so it gets batches of one.
+        group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
+        constexpr int BMAX = 128;
+        const bool own_rng = (next_random == kmcf_rng_next);
+        double *d_u = nullptr, *d_totlog = nullptr;
+        int *d_evlog = nullptr;
+        event_batch_state *d_state = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d_u), 2 * BMAX * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&d_totlog), BMAX * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&d_evlog), 3 * BMAX * sizeof(int)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&d_state), sizeof(event_batch_state)) != hipSuccess) fail(KMCF_ERR_HIP);
+        std::vector<double> h_u(2 * BMAX), h_tot(BMAX);
+        std::vector<int> h_log(3 * BMAX);
+        int B = own_rng ? 4 : 1;
+        while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                      // :418
+            const int nbatch = std::min(B, max_events - nev);
+            if (own_rng) {
+                kmcf_rng peek = *static_cast<kmcf_rng *>(rng_user);
+                for (int q = 0; q < 2 * nbatch; ++q) h_u[q] = peek.distribution(peek.rng);
+            } else {
+                h_u[0] = next_random(rng_user);                                           // :430
+                h_u[1] = next_random(rng_user);                                           // :479
+            }
+            event_batch_state hs = {0, 0};
+            if (hipMemcpyAsync(d_u, h_u.data(), 2 * nbatch * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            for (int ev = 0; ev < nbatch; ++ev) {
+                select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, 0.0, d_gsum, d_tsum, d_prob, d_type,
+                                                                    d_neigh_idx, d_evlog, d_totlog, d_site_element, d_site_charge,
+                                                                    d_aff, ev, d_u, d_state, 1 / freq);
+                tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
+                group_sum_aff_kernel<<<(n_aff + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(n_aff, d_aff, nb, d_tsum, d_gsum);
+            }
+            if (hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(h_log.data(), d_evlog, 3 * nbatch * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(h_tot.data(), d_totlog, nbatch * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            const int n = hs.n_exec;
+            for (int e = 0; e < n && rc == KMCF_OK; ++e) {
+                if (h_event_log) for (int q = 0; q < 3; ++q) h_event_log[3 * (nev + e) + q] = h_log[3 * e + q];
+                t = -std::log(h_u[2 * e + 1]) / h_tot[e];                                 // :479
+                const bool goes_on = t < 1 / freq, device_went_on = (e < n - 1) || hs.done == 0;
+                if (goes_on != device_went_on) {
+                    kmcf_set_error("kmcf_execute_kmc_step: host and device disagree on the end of the step (residence time %.17g, 1/freq %.17g)", t, 1 / freq);
+                    fail(KMCF_ERR_STATE);
+                }
+            }
+            if (own_rng) for (int q = 0; q < 2 * n; ++q) next_random(rng_user);           // consume what was used
+            nev += n;
+            if (rc == KMCF_OK && (hs.done == 2 || n == 0)) {
+                kmcf_set_error("kmcf_execute_kmc_step: no event could be selected (total rate %g)", n < nbatch ? h_tot[n] : 0.0);
+                fail(KMCF_ERR_STATE);
+            }
+            if (own_rng && n == nbatch && hs.done == 0 && B < BMAX) B *= 2;
+        }
+        hipFree(d_u); hipFree(d_totlog); hipFree(d_evlog); hipFree(d_state);
+    }
+    while (!fast && rc == KMCF_OK && t < 1 / freq && nev < max_events) {                 // :418
+        if (M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
         double total = 0.0;
         int ij[3];
         int source_rank = 0;
-        if (fast) {
-            const double u = next_random(rng_user);                                       // :430
-            // three launches per event: select + execute + zero-out, tile sums, group sums
-            select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, u, d_gsum, d_tsum, d_prob, d_type,
-                                                                d_neigh_idx, d_ij, d_tot, d_site_element, d_site_charge, d_aff);
-            tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
-            group_sum_aff_kernel<<<(n_aff + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(n_aff, d_aff, nb, d_tsum, d_gsum);
-            if (hipMemcpyAsync(ij, d_ij, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(&total, d_tot, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
-        } else {
+        {
             total_kernel<<<1, 64, 0, st>>>(ng, d_gsum, d_tot + rank);
             if (kmcf_comm_allgatherv_double(c, d_tot, ones.data(), iota.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }   // MPI_Allgather :423
             if (hipMemcpyAsync(totals.data(), d_tot, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -480,7 +560,7 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                 if (number < 0) number = 0;
                 select_event_kernel<false><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, number, 0.0, d_gsum, d_tsum, d_prob,
                                                                      d_type, d_neigh_idx, d_ij + 3 * rank, d_tot + rank,
-                                                                     nullptr, nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0.0);
             }
             if (kmcf_comm_allgatherv_int(c, d_ij, threes.data(), iota3.data()) != KMCF_OK) { fail(KMCF_ERR_COMM); break; }  // MPI_Bcast :455-459
             if (hipMemcpyAsync(ij, d_ij + 3 * source_rank, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -294,11 +294,17 @@ def execute_kmc_step_mpi(kmc_comm, N, count, displs, nn, neigh_idx, site_layer, 
     nev = C.c_int()
     cap = min(int(max_events), 1 << 16) if return_log else 0
     log = np.zeros(max(3 * cap, 1), np.int32)
-    fn = C.cast(lib.kmcf_rng_next, C.c_void_p)
+    if callable(rng):
+        # any uniform [0, 1) source, like the reference's RandomNumberGenerator& (one host round trip per event:
+        # a foreign generator cannot be drawn ahead and rewound)
+        keep = C.CFUNCTYPE(C.c_double, C.c_void_p)(lambda _user: float(rng()))
+        fn, user = C.cast(keep, C.c_void_p), None
+    else:
+        fn, user = C.cast(lib.kmcf_rng_next, C.c_void_p), rng.handle
     _L.check(lib.kmcf_execute_kmc_step(kmc_comm.handle, int(N), cntp, dspp, int(nn), _ptr(neigh_idx), _ptr(site_layer),
                                        float(T_bg), float(freq), float(sigma), float(k), _ptr(posx), _ptr(posy),
                                        _ptr(posz), _ptr(site_potential_charge), _ptr(site_element), _ptr(site_charge),
-                                       len(layers), egp, erp, evp, eop, fn, rng.handle,
+                                       len(layers), egp, erp, evp, eop, fn, user,
                                        cap if return_log else int(max_events), C.byref(t), C.byref(nev),
                                        log.ctypes.data_as(C.POINTER(C.c_int)) if return_log else None),
              "kmcf_execute_kmc_step")

@@ -56,14 +56,17 @@ def fields5(oracle, dev5, ref5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T_bg,fullscan", [(300.0, False), (150.0, False), (77.0, False), (150.0, True)])
+@pytest.mark.parametrize("T_bg,fullscan", [(300.0, False), (150.0, False), (77.0, False), (150.0, True), (300.0, "callback")])
 def test_kmc_step_matches_oracle(km, oracle, dev5, ref5, fields5, T_bg, fullscan, monkeypatch):
     """Same potentials in, same generator state in: identical event sequence (i, j, type), identical final
     element / charge state, event time to 1e-12.  T_bg scales the rates: 300 K -> hundreds of events per
     step at 5 V, 77 K -> one or two."""
     import torch
     # fullscan: the reference's way of zeroing events (a pass over every slot per event) instead of the
-    # neighbour-list shortcut; both must select the same events
+    # neighbour-list shortcut; both must select the same events.  "callback": a caller-supplied uniform source
+    # (events then go one per host round trip instead of in pre-drawn batches).
+    use_callback = fullscan == "callback"
+    fullscan = fullscan is True
     if fullscan:
         monkeypatch.setenv("KMCF_EVENTS_FULLSCAN", "1")
     else:
@@ -86,7 +89,8 @@ def test_kmc_step_matches_oracle(km, oracle, dev5, ref5, fields5, T_bg, fullscan
     rng = S.RandomNumberGenerator(1)
     t, n, log = S.execute_kmc_step_mpi(comm, N, comm.counts_events, comm.displs_events, 52, i32(ref5["neigh"].reshape(-1)),
                                        i32(lay), T_bg, freq, d["sigma"], d["k"], f64(d["xyz"][:, 0]), f64(d["xyz"][:, 1]),
-                                       f64(d["xyz"][:, 2]), f64(fields5), el, ch, rng, layers, max_events=4096,
+                                       f64(d["xyz"][:, 2]), f64(fields5), el, ch,
+                                       rng.getRandomNumber if use_callback else rng, layers, max_events=4096,
                                        return_log=True)
     assert n == n_o and n >= 1
     assert np.array_equal(log, log_o)

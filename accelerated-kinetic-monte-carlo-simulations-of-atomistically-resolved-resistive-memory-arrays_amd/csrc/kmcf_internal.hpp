@@ -170,7 +170,7 @@ struct kmcf_matrix {
     std::vector<int> h_diag_pos;
     double h_dict[64] = {0.0};         // host copy of d_dict (lives as long as the matrix: async upload source)
     bool dict_uploaded = false;
-    int dict_n = 0;                    // dictionary entries in use (<= 2: register variant of the coded kernel)
+    int dict_n = 0;                    // dictionary entries in use
     int spmv_grid_coded = 0;           // interior grid while coded (its kernel's residency differs)
     int spmv_u = 8;                    // stream: nnz per thread per chunk
     int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction

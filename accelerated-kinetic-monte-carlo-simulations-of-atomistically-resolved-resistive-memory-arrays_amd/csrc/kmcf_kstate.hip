@@ -529,6 +529,8 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
             }
             perm.resize((size_t)n_loc);
             for (int r = 0; r < n_loc; ++r) perm[r] = r;
+            // (sorting the rows of a brick by length, so that the 16 rows of a wavefront in the window SpMV are
+            // equally long, was tried: no gain, 48.5 vs 49.7 us)
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
         }
     }

@@ -189,20 +189,19 @@ __global__ void total_kernel(int ng, const double *__restrict__ gsum, double *__
     *total = s;
 }
 
-// refresh the sums of the groups that hold a tile listed in aff (one thread per entry; duplicates rewrite
-// the same value)
-__global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(int n_aff, const int *__restrict__ aff, int nb,
+// refresh the sums of the groups that hold a tile listed in aff: one block per entry, one thread per tile of
+// the group (duplicates rewrite the same value; a one-thread walk over the 256 tile sums took 20 us)
+__global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(const int *__restrict__ aff, int nb,
                                                                    const double *__restrict__ tsum, double *__restrict__ gsum)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_aff) return;
-    const int tile = aff[t];
-    if (tile < 0) return;
+    static_assert(EV_GROUP == KMCF_BLOCK, "one thread per tile of a group");
+    __shared__ double lds4[4];
+    const int tile = aff[blockIdx.x];
+    if (tile < 0) return;                                      // block-uniform
     const int g = tile / EV_GROUP;
-    const int b0 = g * EV_GROUP, b1 = min(b0 + EV_GROUP, nb);
-    double s = 0.0;
-    for (int b = b0; b < b1; ++b) s += tsum[b];
-    gsum[g] = s;
+    const int b = g * EV_GROUP + threadIdx.x;
+    const double s = block_sum_ev(b < nb ? tsum[b] : 0.0, lds4);
+    if (threadIdx.x == 0) gsum[g] = s;
 }
 
 struct search_lds {
@@ -365,13 +364,18 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
             event_type[own] = (unsigned char)EV_NULL;
             event_prob[own] = 0.0;
             const size_t rb = (size_t)n * nn;
-            for (int q = 0; q < nn; ++q) {
-                const int jj = neigh_idx[rb + q];
-                if (jj == i_del || jj == j_del) { event_type[rb + q] = (unsigned char)EV_NULL; event_prob[rb + q] = 0.0; }
-            }
             aff[2 * t] = (int)(rb / EV_TILE);
             aff[2 * t + 1] = (int)((rb + nn - 1) / EV_TILE);
         }
+    }
+    // the 2 nn x nn slots of the listed neighbours' rows, spread over the whole block
+    for (int idx = threadIdx.x; idx < 2 * nn * nn; idx += KMCF_BLOCK) {
+        const int t = idx / nn, q = idx - t * nn;
+        const int n = neigh_idx[(size_t)(t < nn ? i_del : j_del) * nn + (t % nn)];
+        if (n < 0) continue;
+        const size_t sl = (size_t)n * nn + q;
+        const int jj = neigh_idx[sl];
+        if (jj == i_del || jj == j_del) { event_type[sl] = (unsigned char)EV_NULL; event_prob[sl] = 0.0; }
     }
     if (threadIdx.x < 2) {
         const size_t rb = (size_t)(threadIdx.x == 0 ? i_del : j_del) * nn;
@@ -512,7 +516,7 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                                                                     d_neigh_idx, d_evlog, d_totlog, d_site_element, d_site_charge,
                                                                     d_aff, ev, d_u, d_state, 1 / freq);
                 tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
-                group_sum_aff_kernel<<<(n_aff + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(n_aff, d_aff, nb, d_tsum, d_gsum);
+                group_sum_aff_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(d_aff, nb, d_tsum, d_gsum);
             }
             if (hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(h_log.data(), d_evlog, 3 * nbatch * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||

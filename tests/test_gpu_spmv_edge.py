@@ -1,0 +1,95 @@
+"""GPU: edge shapes through every SpMV kernel (forced with KMCF_SPMV_KIND): tiny matrices, empty rows, rows
+without a diagonal entry, duplicate entries, a dictionary at and beyond its size limit, fewer tiles than the
+kernels' 8-block minimum grid."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _csr(rows):
+    """rows: list of lists of (col, val) -> indptr, indices, data (entries kept in the given order)."""
+    indptr = [0]
+    idx, dat = [], []
+    for r in rows:
+        for c, v in r:
+            idx.append(c)
+            dat.append(v)
+        indptr.append(len(idx))
+    return np.array(indptr, np.int32), np.array(idx, np.int32), np.array(dat, np.float64)
+
+
+def _dense_apply(indptr, indices, data, x):
+    y = np.zeros(len(indptr) - 1)
+    for i in range(len(y)):
+        for j in range(indptr[i], indptr[i + 1]):
+            y[i] += data[j] * x[indices[j]]
+    return y
+
+
+CASES = {
+    "one_row": [[(0, 2.5)]],
+    "diag_only": [[(i, 1.0 + i)] for i in range(7)],
+    "empty_rows": [[(0, 2.0), (1, -1.0)], [], [(1, -1.0), (2, 3.0)], [], [(4, 1.0)]],
+    "no_diagonal": [[(1, -1.0), (2, -0.5)], [(0, -1.0), (1, 4.0)], [(0, -0.5)]],
+    "duplicates": [[(0, 2.0), (1, -1.0), (1, -1.0)], [(0, -1.0), (1, 2.0), (0, -1.0)]],
+}
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_tiny_matrices(km, torch, monkeypatch, name, kind):
+    S = km.solvers
+    monkeypatch.setenv("KMCF_SPMV_KIND", str(kind))
+    indptr, indices, data = _csr(CASES[name])
+    n = len(indptr) - 1
+    comm = S.KMC_comm(n, n, n, n)
+    comm.connect()
+    mat = S.Distributed_matrix(comm, n, [n], [0], indices, indptr, data)
+    info = mat.info()
+    assert info["spmv_kind"] == kind, info
+    if kind == 2:
+        assert info["spmv_coded"] == 1            # few distinct off-diagonal values in every case
+    x = np.linspace(1.0, 2.0, n)
+    p = torch.as_tensor(x, device="cuda")
+    Ap = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+    mat.spmv(p, Ap)
+    np.testing.assert_allclose(Ap.cpu().numpy(), _dense_apply(indptr, indices, data, x), rtol=1e-14, atol=1e-14)
+    np.testing.assert_array_equal(mat.get_values(), data)
+    mat.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("ndistinct,coded", [(1, 1), (62, 1), (63, 0)])
+def test_dictionary_size_limit(km, torch, monkeypatch, ndistinct, coded):
+    """62 distinct off-diagonal values are coded, 63 are not (codes 0..61; 63 marks the diagonal)."""
+    import scipy.sparse as sp
+    S = km.solvers
+    monkeypatch.setenv("KMCF_SPMV_KIND", "2")
+    rng = np.random.default_rng(5)
+    n = 3000
+    vals = -(1.0 + np.arange(ndistinct)) / 64.0
+    diags = [vals[(np.arange(n - o) * 5 + o) % ndistinct] for o in (1, 2, 3, 30)]     # gcd(5, 62) = gcd(5, 63) = 1
+    M = sp.diags(diags, [1, 2, 3, 30], shape=(n, n), format="csr")
+    M = (M + M.T + sp.diags(10.0 + rng.random(n))).tocsr()
+    M.sort_indices()
+    assert len(np.unique(M.data[M.data < 0])) == ndistinct
+    comm = S.KMC_comm(n, n, n, n)
+    comm.connect()
+    mat = S.Distributed_matrix(comm, n, [n], [0], M.indices, M.indptr, M.data)
+    info = mat.info()
+    assert info["spmv_kind"] == 2 and info["spmv_coded"] == coded, info
+    x = rng.standard_normal(n)
+    p = torch.as_tensor(x, device="cuda")
+    Ap = torch.empty_like(p)
+    mat.spmv(p, Ap)
+    np.testing.assert_allclose(Ap.cpu().numpy(), M @ x, rtol=1e-13, atol=1e-13)
+    mat.close()
+    comm.close()

@@ -577,7 +577,7 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
                                double relative_tolerance, int max_iterations, int fixed_iters,
                                kmcf_solve_stats_t *stats)
 {
-    KMCF_CHECK(m && d_r && d_x, KMCF_ERR_ARG, "kmcf_pcg_jacobi: null argument");
+    KMCF_CHECK(m && ((d_r && d_x) || m->n_loc == 0), KMCF_ERR_ARG, "kmcf_pcg_jacobi: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_pcg_jacobi: host-only matrix");
     KMCF_CHECK(max_iterations >= 0 && fixed_iters >= 0, KMCF_ERR_ARG, "kmcf_pcg_jacobi: negative iteration count");
     kmcf_comm *c = m->comm;

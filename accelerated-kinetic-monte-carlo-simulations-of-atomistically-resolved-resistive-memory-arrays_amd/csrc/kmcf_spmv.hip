@@ -894,7 +894,8 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 
 extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
 {
-    KMCF_CHECK(m && d_p && d_Ap, KMCF_ERR_ARG, "kmcf_spmv: null argument");
+    // a rank that owns no rows (fewer rows than ranks) still takes part in the exchange; its vectors may be null
+    KMCF_CHECK(m && ((d_p && d_Ap) || m->n_loc == 0), KMCF_ERR_ARG, "kmcf_spmv: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_HIP(hipSetDevice(c->device));

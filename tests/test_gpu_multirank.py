@@ -141,3 +141,60 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
         assert o["ev_n"] == n_o and np.array_equal(o["ev_log"], log_o)
         assert o["ev_t"] == pytest.approx(t_o, rel=1e-12)
         assert np.array_equal(o["el_after"], el_o) and np.array_equal(o["ch_after"], ch_o)
+
+
+@pytest.mark.parametrize("n,P", [(10, 4), (3, 4), (2000, 3)])
+def test_multirank_generic_matrix_small_and_empty_ranks(km, n, P):
+    """Caller-supplied CSR over P loopback ranks: fewer rows than ranks (a rank owns nothing), a handful of
+    rows per rank, and an uneven partition; distributed SpMV and Jacobi-PCG against the assembled matrix."""
+    import scipy.sparse as sp
+    import torch
+    S = km.solvers
+    M = sp.diags([np.full(n - 1, -1.0), np.full(n, 2.5) + 0.01 * np.arange(n), np.full(n - 1, -1.0)], [-1, 0, 1],
+                 format="csr")
+    if n > 100:
+        M = (M + sp.diags([np.full(n - 37, -0.25)] * 2, [-37, 37])).tocsr()
+    M.sort_indices()
+    counts, displs = S.KMC_comm.partition(n, P)
+    comms = S.KMC_comm.loopback_group(n, n, n, n, size=P, device=0)
+    x = np.cos(np.arange(n) * 0.7) + 2.0
+    b = np.sin(np.arange(n) * 0.3) + 1.5
+    out = [None] * P
+    errs = []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = comms[r]
+            comm.connect()
+            r0, nr = int(displs[r]), int(counts[r])
+            sub = M[r0:r0 + nr]
+            mat = S.Distributed_matrix(comm, n, counts, displs, sub.indices, sub.indptr, sub.data)
+            p = torch.as_tensor(x[r0:r0 + nr].copy(), device="cuda")
+            Ap = torch.empty_like(p)
+            mat.spmv(p, Ap)
+            rr = torch.as_tensor(b[r0:r0 + nr].copy(), device="cuda")
+            xs = torch.zeros(nr, dtype=torch.float64, device="cuda")
+            dinv = torch.as_tensor(1.0 / M.diagonal()[r0:r0 + nr], device="cuda")
+            st = S.conjugate_gradient_jacobi(mat, rr, xs, dinv, 1e-12, 500)
+            out[r] = dict(Ap=Ap.cpu().numpy(), x=xs.cpu().numpy(), st=st, r0=r0, nr=nr)
+            mat.close()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out), "a rank did not finish (deadlock?)"
+    for c in comms:
+        c.close()
+    y = M @ x
+    sol = np.concatenate([o["x"] for o in out])
+    for o in out:
+        np.testing.assert_allclose(o["Ap"], y[o["r0"]:o["r0"] + o["nr"]], rtol=1e-13, atol=1e-13)
+        assert o["st"]["converged"] == 1 and o["st"]["iterations"] == out[0]["st"]["iterations"]
+    assert np.abs(M @ sol - b).max() <= 1e-9

@@ -185,6 +185,7 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    kmcf_event_cache_free(c);
     if (c->nccl) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
     if (c->nccl_red) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_red));
     if (c->ev_packed) hipEventDestroy(c->ev_packed);

@@ -28,6 +28,33 @@ struct kmcf_rng {
     std::uniform_real_distribution<double> distribution{0.0, 1.0};
 };
 
+// Workspace of kmcf_execute_kmc_step, owned by the communicator (kmcf_comm::ev_cache).
+struct kmcf_event_cache {
+    size_t M = 0;                       // event slots of this rank (count * nn)
+    int P = 0, nn = 0;
+    unsigned char *d_type = nullptr;
+    double *d_prob = nullptr, *d_tsum = nullptr, *d_gsum = nullptr, *d_tot = nullptr;
+    int *d_ij = nullptr, *d_aff = nullptr, *d_asym = nullptr;
+    double *d_u = nullptr, *d_totlog = nullptr;     // batch: uniforms in, totals out
+    int *d_evlog = nullptr;
+    void *d_state = nullptr;
+    const int *sym_key = nullptr;       // neighbour list the symmetry verdict belongs to
+    int sym_N = 0;
+    bool symmetric = false;
+};
+
+void kmcf_event_cache_free(kmcf_comm *c)
+{
+    if (!c || !c->ev_cache) return;
+    kmcf_event_cache *w = c->ev_cache;
+    void *ptrs[] = {w->d_type, w->d_prob, w->d_tsum, w->d_gsum, w->d_tot, w->d_ij, w->d_aff, w->d_asym,
+                    w->d_u, w->d_totlog, w->d_evlog, w->d_state};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete w;
+    c->ev_cache = nullptr;
+}
+
 extern "C" int kmcf_rng_create(unsigned int seed, kmcf_rng **out)
 {
     KMCF_CHECK(out, KMCF_ERR_ARG, "kmcf_rng_create: null argument");
@@ -439,18 +466,31 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         E.gen[l] = l < num_layers ? h_E_gen[l] : 0.0; E.rec[l] = l < num_layers ? h_E_rec[l] : 0.0;
         E.vdiff[l] = l < num_layers ? h_E_Vdiff[l] : 0.0; E.odiff[l] = l < num_layers ? h_E_Odiff[l] : 0.0;
     }
-    unsigned char *d_type = nullptr;
-    double *d_prob = nullptr, *d_tsum = nullptr, *d_gsum = nullptr, *d_tot = nullptr;
-    int *d_ij = nullptr, *d_aff = nullptr, *d_asym = nullptr;
     const int n_aff = 4 * nn + 4;
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_type), std::max<size_t>(M, 1)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_prob), std::max<size_t>(M, 1) * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_tsum), (size_t)std::max(nb, 1) * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_gsum), (size_t)ng * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_tot), (size_t)P * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_ij), (size_t)3 * P * sizeof(int)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_aff), (size_t)n_aff * sizeof(int)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_asym), sizeof(int)));
+    // workspace kept on the communicator between steps: the reference allocates and frees its event arrays on
+    // every call (:352-361); at 40 nm that is 0.8 GB per step
+    if (c->ev_cache && (c->ev_cache->M != M || c->ev_cache->P != P || c->ev_cache->nn != nn)) kmcf_event_cache_free(c);
+    if (!c->ev_cache) {
+        kmcf_event_cache *w = new kmcf_event_cache();
+        w->M = M; w->P = P; w->nn = nn;
+        c->ev_cache = w;
+        if (hipMalloc(reinterpret_cast<void **>(&w->d_type), std::max<size_t>(M, 1)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_prob), std::max<size_t>(M, 1) * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_tsum), (size_t)std::max(nb, 1) * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_gsum), (size_t)ng * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_tot), (size_t)P * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_ij), (size_t)3 * P * sizeof(int)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_aff), (size_t)n_aff * sizeof(int)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&w->d_asym), sizeof(int)) != hipSuccess) {
+            kmcf_event_cache_free(c);
+            kmcf_set_error("kmcf_execute_kmc_step: out of device memory for %zu event slots", M);
+            return KMCF_ERR_HIP;
+        }
+    }
+    kmcf_event_cache *w = c->ev_cache;
+    unsigned char *d_type = w->d_type;
+    double *d_prob = w->d_prob, *d_tsum = w->d_tsum, *d_gsum = w->d_gsum, *d_tot = w->d_tot;
+    int *d_ij = w->d_ij, *d_aff = w->d_aff, *d_asym = w->d_asym;
     KMCF_HIP(hipMemsetAsync(d_gsum, 0, (size_t)ng * sizeof(double), st));
     KMCF_HIP(hipMemsetAsync(d_asym, 0, sizeof(int), st));
     std::vector<int> ones(P, 1), iota(P), threes(P, 3), iota3(P);
@@ -466,11 +506,18 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                                                                d_site_charge, E, d_type, d_prob);
         zero_and_sum_kernel<<<nb, KMCF_BLOCK, 0, st>>>(M, start_i, nn, d_neigh_idx, d_type, d_prob, -1, -1, d_tsum);
         if (P == 1 && count == N && !getenv("KMCF_EVENTS_FULLSCAN")) {
-            check_symmetry_kernel<<<(int)g, KMCF_BLOCK, 0, st>>>(N, nn, d_neigh_idx, d_asym);
-            int asym = 1;
-            if (hipMemcpyAsync(&asym, d_asym, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) fail(KMCF_ERR_HIP);
-            fast = (asym == 0);
+            // the neighbour lists are built once per run (kmc_main.cpp:199): the verdict on their symmetry is
+            // kept with the workspace, keyed by the list's address and shape
+            if (w->sym_key != d_neigh_idx || w->sym_N != N) {
+                check_symmetry_kernel<<<(int)g, KMCF_BLOCK, 0, st>>>(N, nn, d_neigh_idx, d_asym);
+                int asym = 1;
+                if (hipMemcpyAsync(&asym, d_asym, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) fail(KMCF_ERR_HIP);
+                w->sym_key = d_neigh_idx;
+                w->sym_N = N;
+                w->symmetric = (asym == 0);
+            }
+            fast = w->symmetric;
         }
     }
     double t = 0.0;
@@ -489,13 +536,14 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
         constexpr int BMAX = 128;
         const bool own_rng = (next_random == kmcf_rng_next);
-        double *d_u = nullptr, *d_totlog = nullptr;
-        int *d_evlog = nullptr;
-        event_batch_state *d_state = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d_u), 2 * BMAX * sizeof(double)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&d_totlog), BMAX * sizeof(double)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&d_evlog), 3 * BMAX * sizeof(int)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&d_state), sizeof(event_batch_state)) != hipSuccess) fail(KMCF_ERR_HIP);
+        if (!w->d_u &&
+            (hipMalloc(reinterpret_cast<void **>(&w->d_u), 2 * BMAX * sizeof(double)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_totlog), BMAX * sizeof(double)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_evlog), 3 * BMAX * sizeof(int)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_state), sizeof(event_batch_state)) != hipSuccess)) fail(KMCF_ERR_HIP);
+        double *d_u = w->d_u, *d_totlog = w->d_totlog;
+        int *d_evlog = w->d_evlog;
+        event_batch_state *d_state = static_cast<event_batch_state *>(w->d_state);
         std::vector<double> h_u(2 * BMAX), h_tot(BMAX);
         std::vector<int> h_log(3 * BMAX);
         int B = own_rng ? 4 : 1;
@@ -540,7 +588,6 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
             }
             if (own_rng && n == nbatch && hs.done == 0 && B < BMAX) B *= 2;
         }
-        hipFree(d_u); hipFree(d_totlog); hipFree(d_evlog); hipFree(d_state);
     }
     while (!fast && rc == KMCF_OK && t < 1 / freq && nev < max_events) {                 // :418
         if (M > 0) group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
@@ -585,7 +632,6 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
     }
     if (rc == KMCF_OK && hipStreamSynchronize(st) != hipSuccess) rc = KMCF_ERR_HIP;
     if (rc == KMCF_ERR_HIP) kmcf_set_error("kmcf_execute_kmc_step: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-    hipFree(d_type); hipFree(d_prob); hipFree(d_tsum); hipFree(d_gsum); hipFree(d_tot); hipFree(d_ij); hipFree(d_aff); hipFree(d_asym);
     *event_time = t;
     if (n_events) *n_events = nev;
     return rc;

@@ -89,7 +89,10 @@ struct kmcf_comm {
     bool force_collectives = false;     // KMCF_FORCE_COMM: 1-rank group still runs the collectives
     bool connected = false;
     int *h_pinned = nullptr;            // 16 ints pinned host (done/iters read-back)
+    // event-step workspace kept between KMC steps (kmcf_execute_kmc_step, kmcf_events.hip)
+    struct kmcf_event_cache *ev_cache = nullptr;
 };
+void kmcf_event_cache_free(kmcf_comm *c);
 
 struct kmcf_matrix {
     kmcf_comm *comm = nullptr;

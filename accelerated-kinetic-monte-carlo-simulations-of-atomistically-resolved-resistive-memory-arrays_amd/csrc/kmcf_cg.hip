@@ -7,7 +7,7 @@
 //  * the reference's 6 hipBLAS calls + 1 Hadamard kernel + 2 host-returning dots
 //    per iteration become 3 kernels (p update | SpMV + p.Ap | x,r,z update + r.z);
 //  * alpha, beta, r.z, p.Ap and the convergence flag live in device memory; the
-//    host enqueues KMCF_CHUNK_ITERS iterations at a time and reads the flag back
+//    host enqueues growing chunks of 2 .. KMCF_CHUNK_ITERS iterations and reads the flag back
 //    once per chunk.  Kernels launched after convergence return at once, so x is
 //    exactly the iterate the reference would have stopped at;
 //  * dot products: one partial per block, summed in a fixed order by every block of
@@ -248,9 +248,13 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
 
     int launched = 0;
     bool done = false;
+    // chunks of 2, 4, 8 ... KMCF_CHUNK_ITERS iterations: a warm-started solve (every KMC step but the first)
+    // stops within a few iterations, and every iteration enqueued behind the stop is three empty launches
+    int chunk_cap = check_tol ? 2 : KMCF_CHUNK_ITERS;
     while (launched < limit && !done) {
         int chunk = limit - launched;
-        if (chunk > KMCF_CHUNK_ITERS) chunk = KMCF_CHUNK_ITERS;
+        if (chunk > chunk_cap) chunk = chunk_cap;
+        chunk_cap = std::min(2 * chunk_cap, KMCF_CHUNK_ITERS);
         for (int i = 0; i < chunk; ++i) {
             const int k = launched + i + 1;  // reference's k
             const int parity = k & 1;
@@ -429,9 +433,11 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
 
     int launched = 0;
     bool done = false;
+    int chunk_cap = check_tol ? 2 : KMCF_CHUNK_ITERS;                  // growing chunks, see pcg_loop
     while (launched < limit && !done) {
         int chunk = limit - launched;
-        if (chunk > KMCF_CHUNK_ITERS) chunk = KMCF_CHUNK_ITERS;
+        if (chunk > chunk_cap) chunk = chunk_cap;
+        chunk_cap = std::min(2 * chunk_cap, KMCF_CHUNK_ITERS);
         for (int i = 0; i < chunk; ++i) {
             const int k = launched + i + 1;
             const int parity = k & 1, first = (k == 1) ? 1 : 0;

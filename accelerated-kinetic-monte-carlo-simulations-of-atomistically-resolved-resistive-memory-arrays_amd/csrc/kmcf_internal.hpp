@@ -194,6 +194,7 @@ struct kmcf_kstate {
     int *d_right_row_ptr = nullptr, *d_right_col = nullptr;
     int *d_diag_pos = nullptr;         // nnz index of the diagonal entry per row
     unsigned char *d_cls = nullptr;    // per-site class (N): 1 metal, 2 uncharged vacancy, 0 other
+    unsigned char *d_cls_col = nullptr;  // the same per internal column (own rows in internal order | halo slots)
     double *d_diag = nullptr, *d_left = nullptr, *d_right = nullptr, *d_rhs = nullptr;
     bool assembled = false;
     // replicated interface solution for sum_and_gather

@@ -239,6 +239,19 @@ __device__ __forceinline__ bool high_rule(unsigned char ci, unsigned char cj)
     return CB ? (((ci | cj) & 1) != 0) : ((ci & cj) != 0);
 }
 
+// Class of every internal column (own rows in internal order, then the halo slots): one gather per column
+// here instead of two dependent gathers (permutation, class) per matrix entry in the assembly.
+__global__ __launch_bounds__(KMCF_BLOCK) void cls_col_kernel(int n_cols, int n_loc, int row_site0, int n_left,
+                                                             const int *__restrict__ perm, const int *__restrict__ halo_gid,
+                                                             const unsigned char *__restrict__ cls,
+                                                             unsigned char *__restrict__ cls_col)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += gridDim.x * blockDim.x) {
+        const int site = (c < n_loc) ? (row_site0 + (perm ? perm[c] : c)) : (n_left + halo_gid[c - n_loc]);
+        cls_col[c] = cls[site];
+    }
+}
+
 template <int LPR, bool CB>
 __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
     int n_loc, int row_site0 /* N_left + displ */, int n_left, int n_interface,
@@ -251,7 +264,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
     double *__restrict__ diag_out, double *__restrict__ left_out, double *__restrict__ right_out,
     double *__restrict__ dinv_out, double *__restrict__ rhs_out,
     unsigned short *__restrict__ idx16 /* window SpMV: value codes above the slot bits, or nullptr */,
-    double *__restrict__ diagv /* window SpMV: diagonal per row, or nullptr */)
+    double *__restrict__ diagv /* window SpMV: diagonal per row, or nullptr */,
+    const unsigned char *__restrict__ cls_col /* class per internal column (cls_col_kernel) */)
 {
     constexpr int SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
     constexpr int RPB = KMCF_BLOCK / LPR;
@@ -263,14 +277,12 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
         int nh = 0, nl = 0, lh = 0, ll = 0, rh = 0, rl = 0;
         int dpos = -1;
         if (valid) {
-            const int ru = perm ? perm[r] : r;            // caller's local row (contact patterns, site index)
-            const unsigned char ci = cls[row_site0 + ru];
+            const int ru = perm ? perm[r] : r;            // caller's local row (contact patterns)
+            const unsigned char ci = cls_col[r];
             dpos = diag_pos[r];
             for (int j = row_ptr[r] + lane; j < row_ptr[r + 1]; j += LPR) {
                 if (j == dpos) continue;
-                const int c = col[j];
-                const int site = (c < n_loc) ? (row_site0 + (perm ? perm[c] : c)) : (n_left + halo_gid[c - n_loc]);
-                const bool high = high_rule<CB>(ci, cls[site]);
+                const bool high = high_rule<CB>(ci, cls_col[col[j]]);
                 val[j] = high ? -high_G : -low_G;
                 if (idx16) idx16[j] = (unsigned short)((idx16[j] & SLOT_MASK) | ((high ? 0 : 1) << KMCF_SLOT_BITS));
                 nh += high; nl += !high;
@@ -306,6 +318,116 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_kernel(
             dinv_out[r] = 1.0 / (d + l + rr);              // inverse_diag :828
             rhs_out[r] = l * VL + rr * VR;                 // calc_rhs_for_A :452
         }
+    }
+}
+
+// The same assembly over the tiles of the window SpMV (matrices planned for the coded kernel: U = 8 entries
+// per lane, <= 64 rows and <= 1024 window columns per tile).  The row-per-16-lanes kernel above touches col,
+// val and idx16 in 64..128-byte pieces and gathers a class per entry from global memory (426 us at 40 nm);
+// here a tile's slot stream comes in as one 16-byte load per lane, the classes of its window columns are
+// staged in LDS, the row lanes (4 per row) turn slots into codes inside LDS and count the conductances, and
+// codes and values go out again as 16- and 64-byte pieces per lane.  Same values, same integer row sums.
+template <bool CB>
+__global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_tile_kernel(
+    int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
+    unsigned short *__restrict__ idx16, double *__restrict__ val, const int *__restrict__ diag_pos,
+    const int *__restrict__ perm, const int *__restrict__ left_row_ptr, const int *__restrict__ left_col,
+    const int *__restrict__ right_row_ptr, const int *__restrict__ right_col, const unsigned char *__restrict__ cls,
+    const unsigned char *__restrict__ cls_col, int n_left, int n_interface, double high_G, double low_G, double VL,
+    double VR, double *__restrict__ diag_out, double *__restrict__ left_out, double *__restrict__ right_out,
+    double *__restrict__ dinv_out, double *__restrict__ rhs_out, double *__restrict__ diagv)
+{
+    constexpr int U = 8, LPR = 4, RPP = KMCF_BLOCK / LPR, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
+    typedef unsigned int pack_t __attribute__((ext_vector_type(U / 2)));
+    __shared__ unsigned char wcls[1 << KMCF_SLOT_BITS];
+    __shared__ pack_t sidx_pk[KMCF_BLOCK];
+    const int tid = threadIdx.x, lane = tid % LPR;
+    unsigned short *sib = reinterpret_cast<unsigned short *>(sidx_pk);
+    for (int c = blockIdx.x; c < n_tiles; c += gridDim.x) {
+        const int2 t0 = tile[c], t1 = tile[c + 1];
+        const int r0 = t0.x, r1 = t1.x, w0 = t0.y, W = t1.y - w0;
+        const int base = row_ptr[r0], cnt = row_ptr[r1] - base;
+        const int abase = base & ~(U - 1);                 // aligned start of the block-wide slot load
+        for (int w = tid; w < W; w += KMCF_BLOCK) wcls[w] = cls_col[wcol[w0 + w]];
+        sidx_pk[tid] = *reinterpret_cast<const pack_t *>(idx16 + abase + U * tid);
+        __syncthreads();
+        double tot = 0.0;
+        int dpos = -1;
+        {                                                  // tiles of this plan hold at most RPP rows: one pass
+            const int r = r0 + tid / LPR;
+            const bool valid = r < r1;
+            int nh = 0, nl = 0, lh = 0, ll = 0, rh = 0, rl = 0;
+            if (valid) {
+                const int ru = perm ? perm[r] : r;        // caller's local row (contact patterns)
+                const unsigned char ci = cls_col[r];
+                dpos = diag_pos[r];
+                for (int j = row_ptr[r] + lane; j < row_ptr[r + 1]; j += LPR) {
+                    const int q = j - abase;
+                    const int slot = sib[q] & SLOT_MASK;
+                    if (j == dpos) { sib[q] = (unsigned short)(slot | (KMCF_CODE_DIAG << KMCF_SLOT_BITS)); continue; }
+                    const bool high = high_rule<CB>(ci, wcls[slot]);
+                    sib[q] = (unsigned short)(slot | ((high ? 0 : 1) << KMCF_SLOT_BITS));
+                    nh += high; nl += !high;
+                }
+                for (int j = left_row_ptr[ru] + lane; j < left_row_ptr[ru + 1]; j += LPR) {
+                    const bool high = high_rule<CB>(ci, cls[left_col[j]]);
+                    lh += high; ll += !high;
+                }
+                for (int j = right_row_ptr[ru] + lane; j < right_row_ptr[ru + 1]; j += LPR) {
+                    const bool high = high_rule<CB>(ci, cls[n_left + n_interface + right_col[j]]);
+                    rh += high; rl += !high;
+                }
+            }
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) {
+                nh += __shfl_xor(nh, off, 64); nl += __shfl_xor(nl, off, 64);
+                lh += __shfl_xor(lh, off, 64); ll += __shfl_xor(ll, off, 64);
+                rh += __shfl_xor(rh, off, 64); rl += __shfl_xor(rl, off, 64);
+            }
+            if (valid && lane == 0) {
+                const double d = (double)nh * high_G + (double)nl * low_G;
+                const double l = (double)lh * high_G + (double)ll * low_G;
+                const double rr = (double)rh * high_G + (double)rl * low_G;
+                tot = d + l + rr;                          // insert_into_diag :807
+                diagv[r] = dpos >= 0 ? tot : 0.0;
+                diag_out[r] = tot;
+                left_out[r] = l;
+                right_out[r] = rr;
+                dinv_out[r] = 1.0 / (d + l + rr);          // inverse_diag :828
+                rhs_out[r] = l * VL + rr * VR;             // calc_rhs_for_A :452
+            } else {
+                dpos = -1;
+            }
+        }
+        __syncthreads();
+        // codes and values back to global memory: lane t owns entries abase + 8 t .. + 7 (16 bytes of codes,
+        // 64 bytes of values); the first and last lanes of a tile share that range with the neighbouring tiles
+        // and write entry-wise.  Diagonal entries get a placeholder here and their value after the barrier.
+        {
+            const int q0 = U * tid, lo = base - abase, hi = lo + cnt;
+            if (q0 + U > lo && q0 < hi) {
+                const pack_t pk = sidx_pk[tid];
+                const unsigned short *e = reinterpret_cast<const unsigned short *>(&pk);
+                if (q0 >= lo && q0 + U <= hi) {
+                    *reinterpret_cast<pack_t *>(idx16 + abase + q0) = pk;
+                    double v[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) v[k] = (e[k] >> KMCF_SLOT_BITS) == 0 ? -high_G : -low_G;
+                    double4 *vp = reinterpret_cast<double4 *>(val + abase + q0);
+                    vp[0] = make_double4(v[0], v[1], v[2], v[3]);
+                    vp[1] = make_double4(v[4], v[5], v[6], v[7]);
+                } else {
+                    for (int k = 0; k < U; ++k) {
+                        const int q = q0 + k;
+                        if (q < lo || q >= hi) continue;
+                        idx16[abase + q] = e[k];
+                        val[abase + q] = (e[k] >> KMCF_SLOT_BITS) == 0 ? -high_G : -low_G;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // orders the placeholder before the value; frees LDS
+        if (lane == 0 && dpos >= 0) val[dpos] = tot;
     }
 }
 
@@ -552,6 +674,7 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
     KMCF_TRY(upload(&k->d_right_col, k->h_right_col));
     const size_t nb = std::max(n_loc, 1) * sizeof(double);
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_cls), std::max(N, 1)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_cls_col), (size_t)std::max(n_loc + k->K->n_halo, 1)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_diag), nb));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_left), nb));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&k->d_right), nb));
@@ -566,7 +689,7 @@ extern "C" int kmcf_kstate_destroy(kmcf_kstate *k)
     if (k->comm && k->comm->device >= 0) {
         hipSetDevice(k->comm->device);
         hipStreamSynchronize(k->comm->stream);
-        void *ptrs[] = {k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_diag_pos, k->d_cls,
+        void *ptrs[] = {k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_diag_pos, k->d_cls, k->d_cls_col,
                         k->d_diag, k->d_left, k->d_right, k->d_rhs, k->d_gather};
         for (void *p : ptrs)
             if (p) hipFree(p);
@@ -612,7 +735,7 @@ extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *
 #define KMCF_ASM_ARGS(VL, VR)                                                                                          \
     m->n_loc, k->N_left + m->row0, k->N_left, k->N_interface, m->d_row_ptr, m->d_col, m->d_val, k->d_diag_pos,          \
         m->d_halo_gid, m->d_perm, k->d_left_row_ptr, k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls,      \
-        high_G, low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs, code_idx, code_diag
+        high_G, low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs, code_idx, code_diag, k->d_cls_col
 
 static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int *d_site_charge,
                             const int *d_metals, int num_metals, double Vd, double high_G, double low_G,
@@ -625,13 +748,27 @@ static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int
     if (m->n_loc > 0) {
         constexpr int LPR = 16;
         const int grid = grid1d((int64_t)m->n_loc * LPR);
+        const int n_cols = m->n_loc + m->n_halo;
+        cls_col_kernel<<<grid1d(n_cols), KMCF_BLOCK, 0, c->stream>>>(n_cols, m->n_loc, k->N_left + m->row0, k->N_left, m->d_perm,
+                                                                    m->d_halo_gid, k->d_cls, k->d_cls_col);
         // window SpMV: the off-diagonals are -high_G / -low_G, so the assembly writes their dictionary codes
         // next to the values and the CG's SpMV streams 2 B/nnz (kmcf_internal.hpp, kmcf_matrix::coded)
         const double dict[2] = {-high_G, -low_G};
         KMCF_TRY(kmcf_matrix_set_dictionary(m, dict, 2));
         unsigned short *code_idx = m->coded ? m->d_idx16 : nullptr;
         double *code_diag = m->coded ? m->d_diagv : nullptr;
-        if (!cb_rule)
+        const bool tiled = m->coded && m->spmv_kind == 2 && m->spmv_u == 8 && m->tiles_for_coded &&
+                           !(getenv("KMCF_ASM_TILED") && atoi(getenv("KMCF_ASM_TILED")) == 0);
+        if (tiled) {
+            const int tgrid = std::min(m->n_tiles, 8 * 256 * 4);
+#define KMCF_ASMT_ARGS(VL, VR)                                                                                          \
+    m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_val, k->d_diag_pos, m->d_perm, k->d_left_row_ptr,   \
+        k->d_left_col, k->d_right_row_ptr, k->d_right_col, k->d_cls, k->d_cls_col, k->N_left, k->N_interface, high_G,   \
+        low_G, VL, VR, k->d_diag, k->d_left, k->d_right, m->d_dinv, k->d_rhs, m->d_diagv
+            if (!cb_rule) k_assemble_tile_kernel<false><<<tgrid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASMT_ARGS(-Vd / 2, Vd / 2));
+            else k_assemble_tile_kernel<true><<<tgrid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASMT_ARGS(Vd / 2, -Vd / 2));
+#undef KMCF_ASMT_ARGS
+        } else if (!cb_rule)
             k_assemble_kernel<LPR, false><<<grid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASM_ARGS(-Vd / 2, Vd / 2));   // :866-867
         else
             k_assemble_kernel<LPR, true><<<grid, KMCF_BLOCK, 0, c->stream>>>(KMCF_ASM_ARGS(Vd / 2, -Vd / 2));    // :697-698

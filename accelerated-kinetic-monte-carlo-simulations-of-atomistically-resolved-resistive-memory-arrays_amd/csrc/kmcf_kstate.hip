@@ -337,7 +337,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void k_assemble_tile_kernel(
     double VR, double *__restrict__ diag_out, double *__restrict__ left_out, double *__restrict__ right_out,
     double *__restrict__ dinv_out, double *__restrict__ rhs_out, double *__restrict__ diagv)
 {
-    constexpr int U = 8, LPR = 4, RPP = KMCF_BLOCK / LPR, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;
+    constexpr int U = 8, LPR = 4, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1;   // KMCF_BLOCK / LPR = 64 rows per pass
     typedef unsigned int pack_t __attribute__((ext_vector_type(U / 2)));
     __shared__ unsigned char wcls[1 << KMCF_SLOT_BITS];
     __shared__ pack_t sidx_pk[KMCF_BLOCK];

@@ -231,33 +231,28 @@ __global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(const int *__
     if (threadIdx.x == 0) gsum[g] = s;
 }
 
-struct search_lds {
-    double wave_tot[4];
-    double acc_found, acc_last;
-    int found, last;
-};
-
-// Block-wide (256 threads) search for the first index k in [0, L) with  acc + (a[0] + ... + a[k]) > number.
-// A thread owns 8 consecutive entries: running sums inside the thread, a block scan of the thread totals on
-// top, so every cumulative sum is formed in one fixed order.  (It is not the order of a one-thread walk: the
-// two can pick different slots only when `number` lies within rounding of a slot boundary.)  If the sums
+// Wave-wide (64 lanes, no barrier) search for the first index k in [0, L) with  acc + (a[0] + ... + a[k]) >
+// number.  A lane owns PER consecutive entries: running sums inside the lane, a shuffle scan of the lane totals
+// on top, so every cumulative sum is formed in one fixed order.  (It is not the order of a one-thread walk:
+// the two can pick different slots only when `number` lies within rounding of a slot boundary.)  If the sums
 // never exceed `number` -- rounding at the very end of the list -- the last entry with a positive value is
 // taken.  Returns the index, or -1 if no entry is positive; *acc becomes the cumulative sum before it.
-__device__ int block_search_256(const double *__restrict__ a, int L, double number, double *acc, search_lds *sh)
+// Every lane of the (fully active) wave gets both.
+template <int PER>
+__device__ int wave_search(const double *__restrict__ a, int L, double number, double *acc)
 {
-    constexpr int PER = 8, SEG = KMCF_BLOCK * PER;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lane = threadIdx.x & 63;
     double base = *acc;
-    if (tid == 0) { sh->found = INT_MAX; sh->last = -1; }
-    __syncthreads();
-    for (int s0 = 0; s0 < L; s0 += SEG) {
+    int last = -1;
+    double last_acc = 0.0;
+    for (int s0 = 0; s0 < L; s0 += 64 * PER) {
         double p[PER];
         double run = 0.0;
         int my_last = -1;
         double my_last_acc = 0.0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int idx = s0 + tid * PER + k;
+            const int idx = s0 + lane * PER + k;
             const double v = idx < L ? a[idx] : 0.0;
             if (v > 0.0) { my_last = idx; my_last_acc = run; }
             run += v;
@@ -271,41 +266,39 @@ __device__ int block_search_256(const double *__restrict__ a, int L, double numb
         }
         double excl = __shfl_up(incl, 1, 64);
         if (lane == 0) excl = 0.0;
-        if (lane == 63) sh->wave_tot[w] = incl;
-        __syncthreads();
-        double wave_off = 0.0;
-        for (int q = 0; q < w; ++q) wave_off += sh->wave_tot[q];
-        const double seg_total = ((sh->wave_tot[0] + sh->wave_tot[1]) + sh->wave_tot[2]) + sh->wave_tot[3];
-        const double mine = base + wave_off + excl;          // cumulative sum before this thread's entries
+        const double seg_total = __shfl(incl, 63, 64);
+        const double mine = base + excl;                      // cumulative sum before this lane's entries
         int cand = INT_MAX;
         double cand_acc = 0.0;
 #pragma unroll
         for (int k = PER - 1; k >= 0; --k) {
-            const int idx = s0 + tid * PER + k;
+            const int idx = s0 + lane * PER + k;
             if (idx < L && mine + p[k] > number) { cand = idx; cand_acc = mine + (k ? p[k - 1] : 0.0); }
         }
-        if (cand != INT_MAX) atomicMin(&sh->found, cand);
-        if (my_last >= 0) atomicMax(&sh->last, my_last);
-        __syncthreads();
-        if (cand != INT_MAX && sh->found == cand) sh->acc_found = cand_acc;
-        if (my_last >= 0 && sh->last == my_last) sh->acc_last = mine + my_last_acc;
-        __syncthreads();
-        if (sh->found != INT_MAX) break;                      // block-uniform
+        const unsigned long long hit = __ballot(cand != INT_MAX);
+        if (hit) {                                            // lanes own ascending ranges: the lowest lane wins
+            const int src = __ffsll((long long)hit) - 1;
+            *acc = __shfl(cand_acc, src, 64);
+            return __shfl(cand, src, 64);
+        }
+        const unsigned long long pos = __ballot(my_last >= 0);
+        if (pos) {
+            const int src = 63 - __clzll((long long)pos);
+            last = __shfl(my_last, src, 64);
+            last_acc = __shfl(mine + my_last_acc, src, 64);
+        }
         base += seg_total;
     }
-    int r = sh->found;
-    if (r != INT_MAX) *acc = sh->acc_found;
-    else { r = sh->last; if (r >= 0) *acc = sh->acc_last; }
-    __syncthreads();                                          // sh is reused by the next search
-    return r;
+    if (last >= 0) *acc = last_acc;
+    return last;
 }
 
 // First slot whose inclusive cumulative sum exceeds the drawn number (thrust::upper_bound on the scan,
 // :444): search the group sums, then the tile sums of that group, then the slots of that tile -- three
-// block-wide searches of one 256-thread block.  number < 0: the number is u * total with u given and the
-// total is formed here (single-rank path: one host sync per event).  FUSED: thread 0 then executes the event
-// (execute_event, :284-331) and the block zeroes the events of the pair through the neighbour lists
-// (zero_rows_kernel) -- one launch instead of three.
+// searches by the first wavefront of the block, no barrier in between.  number < 0: the number is u * total
+// with u given and the total is formed here (single-rank path).  FUSED: lane 0 then executes the event
+// (execute_event, :284-331) and the whole block zeroes the events of the pair through the neighbour lists --
+// one launch instead of three.
 //
 // FUSED launches come in batches without a host round trip in between (the host pre-draws the random numbers):
 // event `ev` of the batch takes its two uniforms from batch_u[2 ev], [2 ev + 1], logs (i, j, type) and the
@@ -324,8 +317,6 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
     int *__restrict__ site_element, int *__restrict__ site_charge, int *__restrict__ aff, int ev,
     const double *__restrict__ batch_u, event_batch_state *__restrict__ state, double inv_freq)
 {
-    __shared__ search_lds sh;
-    __shared__ double lds4[4];
     __shared__ int s_ij[3];
     double total = 0.0;
     if (FUSED) {
@@ -334,44 +325,49 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
         ijevent += 3 * ev;
         total_out += ev;
     }
-    if (number < 0) {
-        double s = 0.0;
-        for (int g = threadIdx.x; g < ng; g += KMCF_BLOCK) s += gsum[g];
-        total = block_sum_ev(s, lds4);
-        if (threadIdx.x == 0) *total_out = total;
-        number = u * total;
-    }
-    double acc = 0.0;
-    int g = block_search_256(gsum, ng, number, &acc, &sh);
-    if (g < 0) g = 0;
-    const int b0 = g * EV_GROUP;
-    int b = block_search_256(tsum + b0, min(EV_GROUP, nb - b0), number, &acc, &sh);
-    b = b0 + (b < 0 ? 0 : b);
-    const size_t id0 = (size_t)b * EV_TILE;
-    const int L = (int)(id0 + EV_TILE < M ? (size_t)EV_TILE : M - id0);
-    int k = block_search_256(event_prob + id0, L, number, &acc, &sh);
-    if (k < 0) k = 0;
-    const size_t id = id0 + k;
-    if (threadIdx.x == 0) {
-        const int i = (int)(id / nn) + start_i, j = neigh_idx[id], et = (int)event_type[id];
-        ijevent[0] = s_ij[0] = i;
-        ijevent[1] = s_ij[1] = j;
-        ijevent[2] = s_ij[2] = et;
-        if (FUSED && j >= 0) {
-            if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
-            else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
-            else if (et == EV_VDIFF || et == EV_ODIFF) {
-                const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
-                const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
-            }
+    if (threadIdx.x < 64) {                                    // the first wavefront selects
+        const int lane = threadIdx.x;
+        if (number < 0) {
+            double s = 0.0;
+            for (int g = lane; g < ng; g += 64) s += gsum[g];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            total = s;
+            if (lane == 0) *total_out = total;
+            number = u * total;
         }
-        if (FUSED) {
-            if (j < 0) {
-                state->done = 2;                               // nothing selectable: the host reports it
-            } else {
-                state->n_exec = ev + 1;
-                const double t_res = -log(batch_u[2 * ev + 1]) / total;
-                if (!(t_res < inv_freq)) state->done = 1;      // this event was the step's last
+        double acc = 0.0;
+        int g = wave_search<4>(gsum, ng, number, &acc);
+        if (g < 0) g = 0;
+        const int b0 = g * EV_GROUP;
+        int b = wave_search<4>(tsum + b0, min(EV_GROUP, nb - b0), number, &acc);
+        b = b0 + (b < 0 ? 0 : b);
+        const size_t id0 = (size_t)b * EV_TILE;
+        const int L = (int)(id0 + EV_TILE < M ? (size_t)EV_TILE : M - id0);
+        int k = wave_search<EV_TILE / 64>(event_prob + id0, L, number, &acc);
+        if (k < 0) k = 0;
+        const size_t id = id0 + k;
+        if (lane == 0) {
+            const int i = (int)(id / nn) + start_i, j = neigh_idx[id], et = (int)event_type[id];
+            ijevent[0] = s_ij[0] = i;
+            ijevent[1] = s_ij[1] = j;
+            ijevent[2] = s_ij[2] = et;
+            if (FUSED && j >= 0) {
+                if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
+                else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
+                else if (et == EV_VDIFF || et == EV_ODIFF) {
+                    const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
+                    const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+                }
+            }
+            if (FUSED) {
+                if (j < 0) {
+                    state->done = 2;                           // nothing selectable: the host reports it
+                } else {
+                    state->n_exec = ev + 1;
+                    const double t_res = -log(batch_u[2 * ev + 1]) / total;
+                    if (!(t_res < inv_freq)) state->done = 1;  // this event was the step's last
+                }
             }
         }
     }

@@ -570,7 +570,7 @@ extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_solve_sparse_CG_Jacobi: host-only matrix");
     KMCF_CHECK(m->comm->nranks == 1, KMCF_ERR_ARG, "kmcf_solve_sparse_CG_Jacobi: single-rank solver (reference: one GPU)");
     kmcf_comm *c = m->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_TRY(kmcf_vec_in(m, m->d_r, d_rhs));
     KMCF_TRY(kmcf_vec_in(m, m->d_x, d_x));
     KMCF_TRY(kmcf_scaled_cg_workspace(m, tol, max_iterations, d_rhs, stats));
@@ -588,7 +588,7 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     KMCF_CHECK(max_iterations >= 0 && fixed_iters >= 0, KMCF_ERR_ARG, "kmcf_pcg_jacobi: negative iteration count");
     kmcf_comm *c = m->comm;
     KMCF_CHECK(c->connected, KMCF_ERR_COMM, "kmcf_pcg_jacobi: communicator not connected");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     // the caller's vectors may be unaligned slices (x is gpubuf.site_potential_boundary +
     // N_left + disp, src/potential_solver_gpu.cu:861) and are in the caller's row order: work on
     // the aligned, internally ordered workspace

@@ -123,6 +123,10 @@ extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int ran
     KMCF_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
     KMCF_HIP(hipEventCreate(&c->ev_t0));
     KMCF_HIP(hipEventCreate(&c->ev_t1));
+    KMCF_HIP(hipEventCreate(&c->ev_a0));
+    KMCF_HIP(hipEventCreate(&c->ev_a1));
+    KMCF_HIP(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), 1024 * sizeof(double)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 16 * sizeof(int), hipHostMallocDefault));
     c->connected = (nranks == 1);
     *out = c;
@@ -192,6 +196,10 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->ev_halo) hipEventDestroy(c->ev_halo);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
+    if (c->ev_a0) hipEventDestroy(c->ev_a0);
+    if (c->ev_a1) hipEventDestroy(c->ev_a1);
+    if (c->ev_entry) hipEventDestroy(c->ev_entry);
+    if (c->d_scratch) hipFree(c->d_scratch);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -209,6 +217,27 @@ extern "C" int kmcf_comm_sync(kmcf_comm *c)
 }
 
 extern "C" void *kmcf_comm_stream(kmcf_comm *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+extern "C" int kmcf_comm_set_caller_stream(kmcf_comm *c, void *stream)
+{
+    KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_set_caller_stream: null comm");
+    c->caller_stream = static_cast<hipStream_t>(stream);
+    return KMCF_OK;
+}
+
+// The library's streams are non-blocking (they must overlap with each other and must not serialise against
+// unrelated null-stream traffic), so nothing orders them after the caller's queued work implicitly.  Every
+// entry point therefore records an event on the caller's stream (the legacy null stream unless
+// kmcf_comm_set_caller_stream named another) and makes the compute stream wait for it.  The way back needs
+// no event: every entry point synchronises its streams before it returns.
+int kmcf_enter(kmcf_comm *c)
+{
+    KMCF_CHECK(c && c->device >= 0, KMCF_ERR_STATE, "host-only communicator");
+    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_HIP(hipEventRecord(c->ev_entry, c->caller_stream));
+    KMCF_HIP(hipStreamWaitEvent(c->stream, c->ev_entry, 0));
+    return KMCF_OK;
+}
 
 // ------------------------------------------------------------------ loopback transport (tests)
 namespace {

@@ -318,12 +318,17 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
     const double *__restrict__ batch_u, event_batch_state *__restrict__ state, double inv_freq)
 {
     __shared__ int s_ij[3];
+    __shared__ int s_done;
     double total = 0.0;
     if (FUSED) {
-        if (state->done) return;                               // block-uniform
+        // one read of the flag for the whole block: lane 0 writes it further down in this same launch, and a
+        // wave scheduled late must not see that write and skip its share of the zero-out
+        if (threadIdx.x == 0) s_done = state->done;
+        __syncthreads();
+        if (s_done) return;
         u = batch_u[2 * ev];
         ijevent += 3 * ev;
-        total_out += ev;
+        total_out += 2 * ev;                                   // (total rate, residence time) per event
     }
     if (threadIdx.x < 64) {                                    // the first wavefront selects
         const int lane = threadIdx.x;
@@ -365,7 +370,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
                     state->done = 2;                           // nothing selectable: the host reports it
                 } else {
                     state->n_exec = ev + 1;
+                    // the device alone decides whether the step goes on; the host takes this t_res as the event
+                    // time it returns (no second evaluation with std::log that could disagree by an ulp)
                     const double t_res = -log(batch_u[2 * ev + 1]) / total;
+                    total_out[1] = t_res;
                     if (!(t_res < inv_freq)) state->done = 1;  // this event was the step's last
                 }
             }
@@ -450,7 +458,7 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                KMCF_ERR_ARG, "kmcf_execute_kmc_step: null argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_execute_kmc_step: host-only communicator");
     KMCF_CHECK(num_layers > 0 && num_layers <= MAX_LAYERS && nn > 0 && freq > 0, KMCF_ERR_ARG, "kmcf_execute_kmc_step: bad sizes");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     hipStream_t st = c->stream;
     const int P = c->nranks, rank = c->rank;
     const int count = h_count[rank], start_i = h_displs[rank];
@@ -534,13 +542,13 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         const bool own_rng = (next_random == kmcf_rng_next);
         if (!w->d_u &&
             (hipMalloc(reinterpret_cast<void **>(&w->d_u), 2 * BMAX * sizeof(double)) != hipSuccess ||
-             hipMalloc(reinterpret_cast<void **>(&w->d_totlog), BMAX * sizeof(double)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_totlog), 2 * BMAX * sizeof(double)) != hipSuccess ||
              hipMalloc(reinterpret_cast<void **>(&w->d_evlog), 3 * BMAX * sizeof(int)) != hipSuccess ||
              hipMalloc(reinterpret_cast<void **>(&w->d_state), sizeof(event_batch_state)) != hipSuccess)) fail(KMCF_ERR_HIP);
         double *d_u = w->d_u, *d_totlog = w->d_totlog;
         int *d_evlog = w->d_evlog;
         event_batch_state *d_state = static_cast<event_batch_state *>(w->d_state);
-        std::vector<double> h_u(2 * BMAX), h_tot(BMAX);
+        std::vector<double> h_u(2 * BMAX), h_tot(2 * BMAX);
         std::vector<int> h_log(3 * BMAX);
         int B = own_rng ? 4 : 1;
         while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                      // :418
@@ -564,22 +572,18 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
             }
             if (hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(h_log.data(), d_evlog, 3 * nbatch * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(h_tot.data(), d_totlog, nbatch * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(h_tot.data(), d_totlog, 2 * nbatch * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
             const int n = hs.n_exec;
-            for (int e = 0; e < n && rc == KMCF_OK; ++e) {
+            for (int e = 0; e < n; ++e)
                 if (h_event_log) for (int q = 0; q < 3; ++q) h_event_log[3 * (nev + e) + q] = h_log[3 * e + q];
-                t = -std::log(h_u[2 * e + 1]) / h_tot[e];                                 // :479
-                const bool goes_on = t < 1 / freq, device_went_on = (e < n - 1) || hs.done == 0;
-                if (goes_on != device_went_on) {
-                    kmcf_set_error("kmcf_execute_kmc_step: host and device disagree on the end of the step (residence time %.17g, 1/freq %.17g)", t, 1 / freq);
-                    fail(KMCF_ERR_STATE);
-                }
-            }
+            // residence time of the last executed event as the device computed it (:479); whether it ends the
+            // step was decided there too (hs.done), so the two can never disagree
+            if (n > 0) t = h_tot[2 * (n - 1) + 1];
             if (own_rng) for (int q = 0; q < 2 * n; ++q) next_random(rng_user);           // consume what was used
             nev += n;
             if (rc == KMCF_OK && (hs.done == 2 || n == 0)) {
-                kmcf_set_error("kmcf_execute_kmc_step: no event could be selected (total rate %g)", n < nbatch ? h_tot[n] : 0.0);
+                kmcf_set_error("kmcf_execute_kmc_step: no event could be selected (total rate %g)", n < nbatch ? h_tot[2 * n] : 0.0);
                 fail(KMCF_ERR_STATE);
             }
             if (own_rng && n == nbatch && hs.done == 0 && B < BMAX) B *= 2;

@@ -84,6 +84,10 @@ struct kmcf_comm {
     hipEvent_t ev_packed = nullptr;     // compute -> comm
     hipEvent_t ev_halo = nullptr;       // comm -> compute
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;   // assembly timing (kmcf_background_potential_sparse)
+    hipEvent_t ev_entry = nullptr;      // caller's stream -> compute stream at every entry point (kmcf_enter)
+    hipStream_t caller_stream = nullptr;  // stream the caller's own work is queued on (default: legacy null stream)
+    double *d_scratch = nullptr;        // 1024 doubles of persistent scratch (heat reduction partials)
     void *nccl = nullptr;               // ncclComm_t: halo send/recv (comm stream)
     void *nccl_red = nullptr;           // ncclComm_t: all-reduce / gathers (compute stream)
     bool force_collectives = false;     // KMCF_FORCE_COMM: 1-rank group still runs the collectives
@@ -223,6 +227,10 @@ int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd);
 int kmcf_halo_exchange_begin(kmcf_matrix *m);   // pack + send/recv on the comm stream
 int kmcf_halo_exchange_end(kmcf_matrix *m);     // compute stream waits for the halo
 // comm.hip
+// First call of every compute entry point: selects the device and orders the library's compute stream after
+// the work the caller has queued so far (buffers filled by kernels or async copies still in flight on the
+// caller's stream are complete before any library kernel reads them).
+int kmcf_enter(kmcf_comm *c);
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count);
 int kmcf_comm_send_recv_halo(kmcf_matrix *m);
 int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);

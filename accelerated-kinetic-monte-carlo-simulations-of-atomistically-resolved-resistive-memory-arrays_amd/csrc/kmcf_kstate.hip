@@ -609,7 +609,7 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
                "kmcf_initialize_sparsity_K: null argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_initialize_sparsity_K: host-only communicator");
     KMCF_CHECK(N > 2 * N_contact && N_contact >= 0, KMCF_ERR_ARG, "kmcf_initialize_sparsity_K: N=%d, N_contact=%d", N, N_contact);
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     const int N_left = N_contact, N_right = N_contact;
     const int N_interface = N - (N_left + N_right);             // iterative_solvers_gpu.cu:271-273
     const int n_loc = h_counts[c->rank], disp = h_displs[c->rank];
@@ -719,7 +719,7 @@ extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *
                "kmcf_update_charge: null argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_update_charge: host-only communicator");
     KMCF_CHECK(nn > 0 && N >= 0, KMCF_ERR_ARG, "kmcf_update_charge: bad sizes");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     const int count = h_count[c->rank], displ = h_displ[c->rank];
     KMCF_CHECK(displ >= 0 && displ + count <= N, KMCF_ERR_ARG, "kmcf_update_charge: rows [%d,%d) outside N=%d", displ, displ + count, N);
     if (count > 0) {
@@ -807,7 +807,7 @@ extern "C" int kmcf_update_CB_edge_sparse(kmcf_kstate *k, const int *d_site_elem
     kmcf_comm *c = k->comm;
     kmcf_matrix *m = k->K;
     KMCF_CHECK(c->nranks == 1, KMCF_ERR_ARG, "kmcf_update_CB_edge_sparse: single-rank solve (the reference runs it on one GPU)");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G, true));
     // (the matrix now holds the CB system: values, diag, rhs; the next kmcf_k_assemble refills K)
     KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, (size_t)m->n_loc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -825,7 +825,7 @@ extern "C" int kmcf_k_assemble(kmcf_kstate *k, const int *d_site_element, const 
                                const int *d_metals, int num_metals, double Vd, double high_G, double low_G)
 {
     KMCF_CHECK(k && d_site_element && d_site_charge && d_metals, KMCF_ERR_ARG, "kmcf_k_assemble: null argument");
-    KMCF_HIP(hipSetDevice(k->comm->device));
+    KMCF_TRY(kmcf_enter(k->comm));
     KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G));
     KMCF_HIP(hipStreamSynchronize(k->comm->stream));
     return KMCF_OK;
@@ -836,7 +836,7 @@ extern "C" int kmcf_k_get_vectors(const kmcf_kstate *k, double *h_diag, double *
 {
     KMCF_CHECK(k, KMCF_ERR_ARG, "kmcf_k_get_vectors: null state");
     KMCF_CHECK(k->assembled, KMCF_ERR_STATE, "kmcf_k_get_vectors: call kmcf_k_assemble first");
-    KMCF_HIP(hipSetDevice(k->comm->device));
+    KMCF_TRY(kmcf_enter(k->comm));
     KMCF_HIP(hipStreamSynchronize(k->comm->stream));
     const int n = k->K->n_loc;
     const size_t bytes = (size_t)n * sizeof(double);
@@ -869,10 +869,8 @@ extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_sit
     kmcf_comm *c = k->comm;
     kmcf_matrix *m = k->K;
     KMCF_CHECK(c->connected, KMCF_ERR_COMM, "kmcf_background_potential_sparse: communicator not connected");
-    KMCF_HIP(hipSetDevice(c->device));
-    hipEvent_t a0, a1;
-    KMCF_HIP(hipEventCreate(&a0));
-    KMCF_HIP(hipEventCreate(&a1));
+    KMCF_TRY(kmcf_enter(c));
+    hipEvent_t a0 = c->ev_a0, a1 = c->ev_a1;   // owned by the communicator: nothing to create or leak per call
     KMCF_HIP(hipEventRecord(a0, c->stream));
     KMCF_TRY(k_assemble_async(k, d_site_element, d_site_charge, d_metals, num_metals, Vd, high_G, low_G));
     KMCF_HIP(hipEventRecord(a1, c->stream));
@@ -891,8 +889,6 @@ extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_sit
         KMCF_HIP(hipEventElapsedTime(&ms, a0, a1));
         stats->ms_assembly = ms;
     }
-    hipEventDestroy(a0);
-    hipEventDestroy(a1);
     return KMCF_OK;
 }
 
@@ -903,7 +899,7 @@ extern "C" int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_pote
     KMCF_CHECK(k && d_site_potential_boundary && d_site_potential_charge, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: null argument");
     KMCF_CHECK(N == k->N && num_atoms_first_layer == k->N_left, KMCF_ERR_ARG, "kmcf_sum_and_gather_potential: size mismatch");
     kmcf_comm *c = k->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     // pairwise term: every rank computed its rows (src/kmc_main.cpp:405-425, potential_solver_gpu.cu:1139-1142)
     if (h_counts_pairwise && h_displs_pairwise)
         KMCF_TRY(kmcf_comm_allgatherv_double(c, d_site_potential_charge, h_counts_pairwise, h_displs_pairwise));
@@ -922,16 +918,14 @@ extern "C" int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site
 {
     KMCF_CHECK(c && d_site_power && d_T_bg && N >= 0, KMCF_ERR_ARG, "kmcf_update_temperature_global: bad argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_update_temperature_global: host-only communicator");
-    KMCF_HIP(hipSetDevice(c->device));
-    double *d_part = nullptr;
+    KMCF_TRY(kmcf_enter(c));
+    double *d_part = c->d_scratch;            // persistent: the reference allocates nothing per call either
     const int g = grid1d(N, 1024);
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_part), (size_t)g * sizeof(double)));
     power_partial_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(d_site_power, N, d_part);
     KMCF_HIP(hipGetLastError());
     temp_update_kernel<<<1, KMCF_BLOCK, 0, c->stream>>>(d_part, g, d_T_bg, a_coeff, b_coeff, number_steps, C_thermal, small_step);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));
-    hipFree(d_part);
     return KMCF_OK;
 }
 
@@ -941,7 +935,7 @@ extern "C" int kmcf_neighbor_list(kmcf_comm *c, const double *d_x, const double 
     KMCF_CHECK(c && d_x && d_y && d_z && d_neigh_idx, KMCF_ERR_ARG, "kmcf_neighbor_list: null argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_neighbor_list: host-only communicator");
     KMCF_CHECK(nn > 0 && nn <= NL_CAP && count >= 0 && displ >= 0 && displ + count <= N, KMCF_ERR_ARG, "kmcf_neighbor_list: bad sizes");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     host_cells hc;
     const double lattice[3] = {1, 1, 1};
     KMCF_TRY(build_cells(d_x, d_y, d_z, N, lattice, 0, nn_dist, &hc));

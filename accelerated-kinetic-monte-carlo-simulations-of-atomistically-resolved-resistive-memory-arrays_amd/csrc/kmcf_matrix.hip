@@ -56,6 +56,11 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
                    (long long)tot, matrix_size);
     }
     kmcf_matrix *m = new kmcf_matrix();
+    // every error return below frees what was built so far (host state and device buffers)
+    struct build_guard {
+        kmcf_matrix *m;
+        ~build_guard() { if (m) kmcf_matrix_destroy(m); }
+    } guard{m};
     m->comm = c;
     m->matrix_size = matrix_size;
     m->counts.assign(counts, counts + P);
@@ -175,7 +180,6 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         for (int i = 0; i < n_loc; ++i) {
             const int r = h_perm[i];
             if (r < 0 || r >= n_loc || inv[r] != -1) {
-                delete m;
                 kmcf_set_error("kmcf_matrix_build: perm is not a permutation of the local rows (entry %d = %d)", i, r);
                 return KMCF_ERR_ARG;
             }
@@ -208,11 +212,12 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     m->h_row_ptr = rp;
 
     if (c->device < 0) {  // host-only planning communicator: no device state
+        guard.m = nullptr;
         *out = m;
         return KMCF_OK;
     }
 
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_TRY(dev_upload(&m->d_row_ptr, rp));
     KMCF_TRY(dev_upload(&m->d_col, col_local));
     if (h_val) {
@@ -259,6 +264,7 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     }
     KMCF_TRY(kmcf_spmv_plan(m));
     if (h_val) KMCF_TRY(kmcf_matrix_encode_from_host(m, val_int.data()));
+    guard.m = nullptr;
     *out = m;
     return KMCF_OK;
 }
@@ -368,7 +374,7 @@ extern "C" int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val)
 {
     KMCF_CHECK(m && h_val, KMCF_ERR_ARG, "kmcf_matrix_set_values: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_set_values: host-only matrix");
-    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_TRY(kmcf_enter(m->comm));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->h_perm.empty()) {
         KMCF_HIP(hipMemcpy(m->d_val, h_val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
@@ -391,7 +397,7 @@ extern "C" int kmcf_matrix_get_values(const kmcf_matrix *m, double *h_val)
 {
     KMCF_CHECK(m && h_val, KMCF_ERR_ARG, "kmcf_matrix_get_values: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_get_values: host-only matrix");
-    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_TRY(kmcf_enter(m->comm));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->h_perm.empty()) {
         KMCF_HIP(hipMemcpy(h_val, m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));

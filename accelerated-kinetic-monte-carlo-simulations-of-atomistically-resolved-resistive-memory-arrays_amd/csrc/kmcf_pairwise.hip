@@ -186,7 +186,7 @@ extern "C" int kmcf_compute_cutoff_list(kmcf_comm *c, const double *d_x, const d
 {
     KMCF_CHECK(c && d_x && d_y && d_z && out && N > 0 && cutoff_radius > 0, KMCF_ERR_ARG, "kmcf_compute_cutoff_list: bad argument");
     KMCF_CHECK(c->device >= 0, KMCF_ERR_STATE, "kmcf_compute_cutoff_list: host-only communicator");
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     std::vector<double> x(N), y(N), z(N);
     KMCF_HIP(hipMemcpy(x.data(), d_x, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
     KMCF_HIP(hipMemcpy(y.data(), d_y, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
@@ -248,7 +248,7 @@ extern "C" int kmcf_poisson_gridless(kmcf_pairwise *p, const double *d_x, const 
     KMCF_CHECK(count >= 0 && displ >= 0 && displ + count <= p->N, KMCF_ERR_ARG, "kmcf_poisson_gridless: rows [%d,%d) outside N=%d",
                displ, displ + count, p->N);
     kmcf_comm *c = p->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     hipStream_t st = c->stream;
     flag_count_kernel<<<p->n_blocks, KMCF_BLOCK, 0, st>>>(p->N, p->d_cell_order, d_site_charge, p->d_block_sum);
     block_sum_scan_kernel<<<1, KMCF_BLOCK, 0, st>>>(p->n_blocks, p->d_block_sum);

@@ -898,7 +898,7 @@ extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
     KMCF_CHECK(m && ((d_p && d_Ap) || m->n_loc == 0), KMCF_ERR_ARG, "kmcf_spmv: null argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv: host-only matrix");
     kmcf_comm *c = m->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_TRY(kmcf_vec_in(m, m->d_p, d_p));
     KMCF_TRY(kmcf_spmv_device(m, false, false));
     KMCF_TRY(kmcf_vec_out(m, d_Ap, m->d_Ap));
@@ -911,7 +911,7 @@ extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms
     KMCF_CHECK(m && reps > 0 && ms_total, KMCF_ERR_ARG, "kmcf_spmv_bench: bad argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv_bench: host-only matrix");
     kmcf_comm *c = m->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_HIP(hipEventRecord(c->ev_t0, c->stream));
     for (int i = 0; i < reps; ++i) KMCF_TRY(kmcf_spmv_device(m, with_dot != 0, false));
     KMCF_HIP(hipEventRecord(c->ev_t1, c->stream));
@@ -928,7 +928,7 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
     KMCF_CHECK(m && reps > 0 && ms_total && kind >= 0 && kind <= 2, KMCF_ERR_ARG, "kmcf_comm_bench: bad argument");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_comm_bench: host-only matrix");
     kmcf_comm *c = m->comm;
-    KMCF_HIP(hipSetDevice(c->device));
+    KMCF_TRY(kmcf_enter(c));
     KMCF_HIP(hipMemsetAsync(&m->d_S->red[0], 0, 3 * sizeof(double), c->stream));
     KMCF_HIP(hipEventRecord(c->ev_t0, c->stream));
     for (int i = 0; i < reps; ++i) {
@@ -953,7 +953,7 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
 extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
 {
     KMCF_CHECK(m && m->d_val, KMCF_ERR_ARG, "kmcf_spmv_replan: bad matrix");
-    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_TRY(kmcf_enter(m->comm));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->d_chunk_row) { hipFree(m->d_chunk_row); m->d_chunk_row = nullptr; }
     if (m->d_tile) { hipFree(m->d_tile); m->d_tile = nullptr; }
@@ -977,6 +977,7 @@ extern "C" int kmcf_pack(kmcf_comm *c, double *d_packed, const double *d_unpacke
 {
     KMCF_CHECK(c && n >= 0, KMCF_ERR_ARG, "kmcf_pack: bad argument");
     if (n == 0) return KMCF_OK;
+    KMCF_TRY(kmcf_enter(c));
     pack_kernel<<<grid_for(n, KMCF_BLOCK), KMCF_BLOCK, 0, c->stream>>>(d_packed, d_unpacked, d_indices, n, nullptr, 0);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));
@@ -987,6 +988,7 @@ extern "C" int kmcf_unpack(kmcf_comm *c, double *d_unpacked, const double *d_pac
 {
     KMCF_CHECK(c && n >= 0, KMCF_ERR_ARG, "kmcf_unpack: bad argument");
     if (n == 0) return KMCF_OK;
+    KMCF_TRY(kmcf_enter(c));
     unpack_kernel<<<grid_for(n, KMCF_BLOCK), KMCF_BLOCK, 0, c->stream>>>(d_unpacked, d_packed, d_indices, n);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));
@@ -997,6 +999,7 @@ extern "C" int kmcf_unpack_add(kmcf_comm *c, double *d_unpacked, const double *d
 {
     KMCF_CHECK(c && n >= 0, KMCF_ERR_ARG, "kmcf_unpack_add: bad argument");
     if (n == 0) return KMCF_OK;
+    KMCF_TRY(kmcf_enter(c));
     unpack_add_kernel<<<grid_for(n, KMCF_BLOCK), KMCF_BLOCK, 0, c->stream>>>(d_unpacked, d_packed, d_indices, n);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));
@@ -1007,6 +1010,7 @@ extern "C" int kmcf_elementwise_vector_vector(kmcf_comm *c, const double *d_a, c
 {
     KMCF_CHECK(c && n >= 0, KMCF_ERR_ARG, "kmcf_elementwise_vector_vector: bad argument");
     if (n == 0) return KMCF_OK;
+    KMCF_TRY(kmcf_enter(c));
     hadamard_kernel<<<grid_for(n, KMCF_BLOCK), KMCF_BLOCK, 0, c->stream>>>(d_a, d_b, d_out, n);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));

@@ -14,6 +14,16 @@
  * (the reference aborts: src/utils.h:145-154, dist_iterative/cudaerrchk.h:12-75).
  * The C++ shim in kmcfield_compat.hpp restores abort-on-error for drop-in use.
  *
+ * Stream ordering contract: device work of the library runs on its own non-blocking
+ * HIP streams.  On entry every compute function orders its stream after everything the
+ * caller has queued so far on the caller's stream -- the legacy null stream (what the
+ * reference's kernels and plain hipMemcpy use, and PyTorch's default stream) unless
+ * kmcf_comm_set_caller_stream() named another -- so buffers written by kernels or
+ * asynchronous copies still in flight are complete before the library reads them.  On
+ * return every function has synchronised its streams: results are visible to any stream
+ * (the reference's contract, hipDeviceSynchronize at dist_conjugate_gradient.cpp:271).
+ * Work queued on OTHER streams than the declared one must be synchronised by the caller.
+ *
  * Process model: one process per GPU.  A kmcf_comm is this process's member of
  * the solver group (the reference's MPI communicator comm_K, src/KMC_comm.h:
  * 132-289).  Multi-rank groups exchange halos and dot products with RCCL.
@@ -62,6 +72,9 @@ int kmcf_comm_destroy(kmcf_comm *c);
 int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks);
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
+/* Declares the hipStream_t the caller queues its own device work on (NULL = legacy null
+ * stream, the default); see "Stream ordering contract" above. */
+int kmcf_comm_set_caller_stream(kmcf_comm *c, void *hip_stream);
 
 /* Block-row partition rule of the reference (src/KMC_comm.h:249-263,
  * dist_iterative_test/utils.cpp:3-23). */

@@ -303,3 +303,136 @@ def poisson_gridless(xyz, charge, sigma, k, cutoff=20.0, count=None, displ=0):
     pot = np.zeros(N)
     lib().orc_poisson_gridless(x, y, z, N, _i(charge), sigma, k, cutoff, count, displ, pot)
     return pot
+
+
+# ---------------------------------------------------------------------------------------------
+# T path (current solve): oracle/kmcf_oracle_T.c.  PARITY UNPINNED by any reference fixture.
+# ---------------------------------------------------------------------------------------------
+class TSystem:
+    """Everything the reference's update_power_gpu_sparse_dist assembles for one KMC step, on one rank
+    (src/current_solver_gpu.cu:1430-1655): atom arrays, neighbour matrix (pattern, values, diagonal), tunnel
+    sub-block (points, pattern, values, diagonal), preconditioner and right-hand side."""
+
+    def __init__(self, xyz, site_element, site_charge, site_CB_edge, metals, nn_dist, n_inj, n_ext,
+                 num_layers_contact, Vd, high_G, low_G, loop_G, tol, m_e, V0, x_lo=-4.2, x_hi=52.65):
+        L = lib()
+        L.orc_T_atoms.restype = C.c_int
+        L.orc_T_atoms.argtypes = [_ip, C.c_int, _ip]
+        L.orc_T_pattern.restype = C.c_int64
+        L.orc_T_pattern.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _ip, C.c_void_p]
+        L.orc_T_values.argtypes = [_dp, _dp, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, _dp, _dp]
+        L.orc_T_tunnel_points.restype = C.c_int
+        L.orc_T_tunnel_points.argtypes = [_ip, _dp, C.c_int, C.c_double, C.c_double, _ip]
+        L.orc_T_tunnel_pattern.restype = C.c_int64
+        L.orc_T_tunnel_pattern.argtypes = [_dp, _dp, _dp, _dp, _ip, _ip, C.c_int, C.c_int, C.c_double, C.c_double,
+                                           _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_void_p]
+        L.orc_T_tunnel_values.argtypes = [_dp, _dp, _dp, _dp, _ip, _ip, C.c_int, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip,
+                                          _dp, _dp]
+        site_element = _i(site_element)
+        N = len(site_element)
+        atom_site = np.zeros(N, np.int32)
+        self.N_atom = L.orc_T_atoms(site_element, N, atom_site)
+        self.atom_site = atom_site[:self.N_atom].copy()
+        a = self.atom_site
+        self.ax, self.ay, self.az = _f(xyz[a, 0]), _f(xyz[a, 1]), _f(xyz[a, 2])
+        self.atom_element = _i(site_element[a])
+        self.atom_charge = _i(np.asarray(site_charge)[a])
+        self.atom_CB_edge = _f(np.asarray(site_CB_edge)[a])
+        self.metals = _i(metals)
+        Na = self.N_atom
+        self.Nsub = Na + 1
+        self.params = dict(nn_dist=nn_dist, n_inj=n_inj, n_ext=n_ext, num_layers_contact=num_layers_contact, Vd=Vd,
+                           high_G=high_G, low_G=low_G, loop_G=loop_G, tol=tol, m_e=m_e, V0=V0)
+        # neighbour matrix
+        self.row_ptr = np.zeros(self.Nsub + 1, np.int32)
+        nnz = L.orc_T_pattern(self.ax, self.ay, self.az, Na, nn_dist, n_inj, n_ext, self.row_ptr, None)
+        self.col = np.zeros(max(int(nnz), 1), np.int32)
+        L.orc_T_pattern(self.ax, self.ay, self.az, Na, nn_dist, n_inj, n_ext, self.row_ptr,
+                        self.col.ctypes.data_as(C.c_void_p))
+        self.col = self.col[:nnz]
+        self.val = np.zeros(nnz)
+        self.diag_neigh = np.zeros(self.Nsub)
+        L.orc_T_values(self.ax, self.ay, self.az, self.atom_element, self.atom_charge, self.metals, len(self.metals),
+                       Na, nn_dist, high_G, low_G, loop_G, n_inj, n_ext, self.row_ptr, self.col, self.val,
+                       self.diag_neigh)
+        # tunnel sub-block (the reference hard-codes num_metals = 2 here, initialize_sparsity_T.cu:800)
+        tidx = np.zeros(max(Na, 1), np.int32)
+        self.n_t = L.orc_T_tunnel_points(self.atom_element, self.ax, Na, x_lo, x_hi, tidx)
+        self.tunnel_idx = tidx[:self.n_t].copy()
+        nt = self.n_t
+        self.sub_row_ptr = np.zeros(nt + 1, np.int32)
+        targs = (self.ax, self.ay, self.az, self.atom_CB_edge, self.atom_element, self.metals, len(self.metals), Na,
+                 nn_dist, tol)
+        snnz = L.orc_T_tunnel_pattern(*targs, _i(self.tunnel_idx) if nt else np.zeros(1, np.int32), nt,
+                                      num_layers_contact, n_inj, n_ext, self.sub_row_ptr, None)
+        self.sub_col = np.zeros(max(int(snnz), 1), np.int32)
+        L.orc_T_tunnel_pattern(*targs, _i(self.tunnel_idx) if nt else np.zeros(1, np.int32), nt, num_layers_contact,
+                               n_inj, n_ext, self.sub_row_ptr, self.sub_col.ctypes.data_as(C.c_void_p))
+        self.sub_val = np.zeros(max(int(snnz), 1))
+        self.diag_tunnel = np.zeros(max(nt, 1))
+        L.orc_T_tunnel_values(*targs, m_e, V0, _i(self.tunnel_idx) if nt else np.zeros(1, np.int32), nt,
+                              num_layers_contact, n_inj, n_ext, self.sub_row_ptr, self.sub_col, self.sub_val,
+                              self.diag_tunnel)
+        self.sub_col, self.sub_val, self.diag_tunnel = self.sub_col[:snnz], self.sub_val[:snnz], self.diag_tunnel[:nt]
+        self.sub_rows = _i(self.tunnel_idx + 2)          # shift_vector_by_constant, initialize_sparsity_T.cu:904
+        # preconditioner (assemble_preconditioner + invert_diag, current_solver_gpu.cu:1323-1338) and rhs (:1627-1632)
+        d = self.diag_neigh.copy()
+        d[self.sub_rows] += self.diag_tunnel
+        self.diag = d
+        self.dinv = 1 / d
+        self.rhs = np.zeros(self.Nsub)
+        self.rhs[0] = -loop_G * Vd
+        self.rhs[1] = loop_G * Vd
+
+    def _sub(self):
+        z1 = np.zeros(1, np.int32)
+        return (self.n_t, self.sub_row_ptr, self.sub_col if len(self.sub_col) else z1,
+                self.sub_val if len(self.sub_val) else np.zeros(1), self.sub_rows if self.n_t else z1)
+
+    def spmv(self, x):
+        L = lib()
+        L.orc_T_spmv_split.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _dp, _dp]
+        y = np.zeros(self.Nsub)
+        L.orc_T_spmv_split(self.Nsub, self.row_ptr, self.col, self.val, *self._sub(), _f(x), y)
+        return y
+
+    def solve(self, x0, tol, max_it):
+        """conjugate_gradient_jacobi_split_sparse: returns (x, iterations, relres)."""
+        L = lib()
+        L.orc_T_pcg_split.restype = C.c_int
+        L.orc_T_pcg_split.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _dp, _dp, _dp, C.c_double,
+                                      C.c_int, C.POINTER(C.c_double)]
+        r = self.rhs.copy()
+        x = _f(x0).copy()
+        rel = C.c_double()
+        it = L.orc_T_pcg_split(self.Nsub, self.row_ptr, self.col, self.val, *self._sub(), r, x, self.dinv, float(tol),
+                               int(max_it), C.byref(rel))
+        return x, it, rel.value
+
+    def imacro(self, m):
+        L = lib()
+        L.orc_T_imacro.restype = C.c_double
+        L.orc_T_imacro.argtypes = [_ip, _ip, _dp, _dp]
+        return L.orc_T_imacro(self.row_ptr, self.col, self.val, _f(m))
+
+    def power(self, m, alpha, site_power):
+        """m: N_atom + 2 potentials already scaled by G0 (shifted in place); writes site_power in place."""
+        L = lib()
+        L.orc_T_power.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _dp, C.c_double, C.c_double,
+                                  _ip, _ip, _ip, C.c_int, _dp]
+        n_t, srp, scol, sval, _ = self._sub()
+        L.orc_T_power(self.N_atom, self.row_ptr, self.col, self.val, n_t, srp, scol, sval,
+                      _i(self.tunnel_idx) if n_t else np.zeros(1, np.int32), m, self.params["Vd"], alpha,
+                      self.atom_element, self.atom_site, self.metals, len(self.metals), site_power)
+        return site_power
+
+    def merged_csr(self):
+        """The monolithic operator A_n + P^T S P as scipy CSR (for dense cross-checks)."""
+        import scipy.sparse as sp
+        A = sp.csr_matrix((self.val, self.col, self.row_ptr), shape=(self.Nsub, self.Nsub))
+        if self.n_t:
+            S = sp.csr_matrix((self.sub_val, self.sub_col, self.sub_row_ptr), shape=(self.n_t, self.n_t)).tocoo()
+            A = A + sp.coo_matrix((S.data, (self.sub_rows[S.row], self.sub_rows[S.col])), shape=A.shape).tocsr()
+        return A

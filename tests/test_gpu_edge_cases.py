@@ -147,3 +147,35 @@ def test_authors_binary_matrix_format(km, torch, tmp_path):
     assert np.abs(xs - sysd["solution"]).sum() / np.abs(sysd["solution"]).sum() <= 1e-9
     mat.close()
     comm.close()
+
+
+def test_entry_points_wait_for_the_callers_queued_work(km, torch):
+    """Stream ordering contract (include/kmcfield.h): the library's non-blocking streams are ordered after
+    the work the caller has queued on its own stream.  Here ~40 ms of small kernels that build the input
+    vector are still in flight on torch's default stream when kmcf_spmv is called; without the entry event
+    the SpMV would read a half-built vector.  Also through a declared non-default caller stream."""
+    import scipy.sparse as sp
+    S = km.solvers
+    n = 200000
+    M = (sp.diags([-1.0, -1.0], [-1, 1], shape=(n, n)) + sp.diags(np.full(n, 4.0))).tocsr()
+    M.sort_indices()
+    comm = _comm(km, n)
+    mat = S.Distributed_matrix(comm, n, [n], [0], M.indices, M.indptr, M.data)
+    want = M @ np.ones(n)
+    lib = km.lib.load()
+    for use_side_stream in (False, True):
+        side = torch.cuda.Stream() if use_side_stream else None
+        if side is not None:
+            km.lib.check(lib.kmcf_comm_set_caller_stream(comm.handle, side.cuda_stream), "set_caller_stream")
+        with torch.cuda.stream(side) if side is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            p = torch.zeros(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(4000):
+                p += 0.00025                     # 4000 launches queued, not yet executed
+            Ap = torch.empty_like(p)
+            mat.spmv(p, Ap)
+        got = Ap.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+    km.lib.check(lib.kmcf_comm_set_caller_stream(comm.handle, None), "set_caller_stream")
+    mat.close()
+    comm.close()

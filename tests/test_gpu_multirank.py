@@ -85,8 +85,14 @@ def _run_ranks(km, d, P, ref_charge):
     return out
 
 
+@pytest.mark.parametrize("variant", ["classic", "cg1r"])
 @pytest.mark.parametrize("P", [2, 4])
-def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
+def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P, variant, monkeypatch):
+    # classic = the reference's recurrence (dist_conjugate_gradient.cpp:217-266), what the oracle's P-rank
+    # emulation runs: iteration count within the +-2 % BASELINE.md promises.  cg1r = the single-reduction
+    # (Chronopoulos-Gear) recurrence multi-rank groups use by default: the same Krylov iterates only in exact
+    # arithmetic, so its count is held to +-5 % and its solution to the same bounds as the classic one.
+    monkeypatch.setenv("KMCF_CG_VARIANT", variant)
     d = dev5
     NL = d["N_contact"]
     ks, A = ref5["ks"], ref5["A"]
@@ -112,7 +118,7 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P):
     its = {o["st"]["iterations"] for o in out}
     assert len(its) == 1
     it = its.pop()
-    assert abs(it - ito) <= 0.05 * ito, (it, ito)      # see tests/test_gpu_parity.py on this tolerance
+    assert abs(it - ito) <= (0.02 if variant == "classic" else 0.05) * ito, (variant, it, ito)
     for o in out:
         assert o["st"]["converged"] == 1 and o["st"]["relres"] <= ref5["tol"]
         # after sum_and_gather every rank holds the full interface solution

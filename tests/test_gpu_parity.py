@@ -135,7 +135,7 @@ def test_pcg_matches_oracle(km, sys5, ref5, torch_cuda, oracle):
     dinv = torch.as_tensor(A["dinv"], device="cuda")
     st = S.conjugate_gradient_jacobi(mat, r, x, dinv, ref5["tol"], 10000)
     assert st["converged"] == 1
-    assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"], (st, ref5["iters"])
+    assert abs(st["iterations"] - ref5["iters"]) <= 0.02 * ref5["iters"], (st, ref5["iters"])
     assert st["relres"] <= ref5["tol"]
     xg = x.cpu().numpy()
     dx = np.abs(xg - ref5["x"])
@@ -186,7 +186,7 @@ def test_background_potential_end_to_end(km, sys5, ref5):
     st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                            d["nn_dist"], len(d["metals"]), 0)
     assert st["converged"] == 1
-    assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"]
+    assert abs(st["iterations"] - ref5["iters"]) <= 0.02 * ref5["iters"]
     v = buf.site_potential_boundary.cpu().numpy()
     assert np.all(v[:NL] == 0) and np.all(v[-NL:] == 0)        # contacts are not written
     assert np.abs(v[NL:-NL] - ref5["x"]).max() <= 5e-4
@@ -303,6 +303,8 @@ def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle):
     finally:
         del os.environ["KMCF_CG_VARIANT"]
     assert st["converged"] == 1 and st["relres"] <= ref5["tol"]
+    # a different recurrence (Chronopoulos-Gear): the same iterates only in exact arithmetic, so the count is
+    # held to 5 % here; the classic loop above is held to the 2 % BASELINE.md promises
     assert abs(st["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"], (st["iterations"], ref5["iters"])
     xg = x.cpu().numpy()
     dx = np.abs(xg - ref5["x"])

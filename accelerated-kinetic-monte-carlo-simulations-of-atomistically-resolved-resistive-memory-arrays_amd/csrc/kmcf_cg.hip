@@ -40,22 +40,29 @@ __device__ __forceinline__ double block_sum(double v, double *lds4)
     return t;
 }
 
-// Sum of two partial arrays in a fixed order; every thread of the block gets the result.
-__device__ __forceinline__ double reduce_partials(const double *__restrict__ a, int na,
-                                                  const double *__restrict__ b, int nb, double *lds4)
+// Up to four partial arrays (an SpMV writes one per pass: interior rows, boundary rows, long rows, sub-block).
+struct part_ref {
+    const double *p[4];
+    int n[4];
+};
+
+part_ref pr1(const double *a, int na) { return part_ref{{a, nullptr, nullptr, nullptr}, {na, 0, 0, 0}}; }
+part_ref pr_none() { return pr1(nullptr, 0); }
+part_ref pr_spmv(const kmcf_matrix *m)
 {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < na; i += KMCF_BLOCK) v += a[i];
-    for (int i = threadIdx.x; i < nb; i += KMCF_BLOCK) v += b[i];
-    return block_sum(v, lds4);
+    const kmcf_part4 q = kmcf_spmv_partials(m);
+    return part_ref{{q.p[0], q.p[1], q.p[2], q.p[3]}, {q.n[0], q.n[1], q.n[2], q.n[3]}};
 }
 
-struct part_ref {
-    const double *a;
-    int na;
-    const double *b;
-    int nb;
-};
+// Sum of the partial arrays in a fixed order; every thread of the block gets the result.
+__device__ __forceinline__ double reduce_partials(const part_ref &r, double *lds4)
+{
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int i = threadIdx.x; i < r.n[q]; i += KMCF_BLOCK) v += r.p[q][i];
+    return block_sum(v, lds4);
+}
 
 // r = b - A x0 ; z = r .* dinv ; partial r.z and b.b   (dist_conjugate_gradient.cpp:187, 201-212)
 template <bool PRECOND>
@@ -84,10 +91,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_finalize_kernel(part_ref p0, in
 {
     __shared__ double lds4[4];
     if (check_done && S->done) return;
-    double t0 = reduce_partials(p0.a, p0.na, p0.b, p0.nb, lds4);
+    double t0 = reduce_partials(p0, lds4);
     if (threadIdx.x == 0) S->red[slot0] = t0;
     if (slot1 >= 0) {
-        double t1 = reduce_partials(p1.a, p1.na, p1.b, p1.nb, lds4);
+        double t1 = reduce_partials(p1, lds4);
         if (threadIdx.x == 0) S->red[slot1] = t1;
     }
 }
@@ -101,9 +108,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
 {
     __shared__ double lds4[4];
     if (S->done) return;
-    const double rz_new = reduce_partials(prz.a, prz.na, prz.b, prz.nb, lds4);
+    const double rz_new = reduce_partials(prz, lds4);
     double bb;
-    if (first) bb = reduce_partials(pbb.a, pbb.na, pbb.b, pbb.nb, lds4);
+    if (first) bb = reduce_partials(pbb, lds4);
     else bb = S->bb;
     // check_tol: 0 fixed iteration count; 1 relative rule r.z/b.b > tol^2 (:217);
     // 2 absolute rule of solve_sparse_CG_Jacobi (src/iterative_solvers_gpu.cu:838-840, 858):
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
 {
     __shared__ double lds4[4];
     if (S->done) return;
-    const double pAp = reduce_partials(ppap.a, ppap.na, ppap.b, ppap.nb, lds4);
+    const double pAp = reduce_partials(ppap, lds4);
     const double a = S->rz[parity] / pAp;
     const double na = -a;
     double rz = 0.0;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_tail_kernel(part_ref prz, kmcf_
 {
     __shared__ double lds4[4];
     if (S->done) return;
-    double t = reduce_partials(prz.a, prz.na, prz.b, prz.nb, lds4);
+    double t = reduce_partials(prz, lds4);
     if (threadIdx.x == 0) S->rz_last = t;
 }
 
@@ -226,12 +233,12 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     const int limit = fixed_iters > 0 ? fixed_iters : max_it;
 
     // partial sources: local partial arrays, or the all-reduced scalar in S->red
-    part_ref prz_loc{m->d_part_b, vg, nullptr, 0};
-    part_ref pbb_loc{m->d_part_c, vg, nullptr, 0};
-    part_ref ppap_loc{m->d_part_a, kmcf_interior_grid(m), m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
-    part_ref prz = multi ? part_ref{&S->red[0], 1, nullptr, 0} : prz_loc;
-    part_ref pbb = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pbb_loc;
-    part_ref ppap = multi ? part_ref{&S->red[2], 1, nullptr, 0} : ppap_loc;
+    part_ref prz_loc = pr1(m->d_part_b, vg);
+    part_ref pbb_loc = pr1(m->d_part_c, vg);
+    part_ref ppap_loc = pr_spmv(m);
+    part_ref prz = multi ? pr1(&S->red[0], 1) : prz_loc;
+    part_ref pbb = multi ? pr1(&S->red[1], 1) : pbb_loc;
+    part_ref ppap = multi ? pr1(&S->red[2], 1) : ppap_loc;
 
     KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
@@ -263,7 +270,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
             KMCF_HIP(hipGetLastError());
             KMCF_TRY(kmcf_spmv_device(m, true, true));
             if (multi) {
-                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(ppap_loc, 2, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(ppap_loc, 2, pr_none(), -1, S, 1);
                 KMCF_HIP(hipGetLastError());
                 KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[2], 1));
             }
@@ -271,7 +278,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
                                                              parity, m->d_part_b);
             KMCF_HIP(hipGetLastError());
             if (multi) {
-                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz_loc, 0, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+                cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz_loc, 0, pr_none(), -1, S, 1);
                 KMCF_HIP(hipGetLastError());
                 KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 1));
             }
@@ -350,10 +357,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
 {
     __shared__ double lds4[4];
     if (S->done) return;
-    const double gamma = reduce_partials(pgamma.a, pgamma.na, pgamma.b, pgamma.nb, lds4);
-    const double delta = reduce_partials(pdelta.a, pdelta.na, pdelta.b, pdelta.nb, lds4);
+    const double gamma = reduce_partials(pgamma, lds4);
+    const double delta = reduce_partials(pdelta, lds4);
     double bb;
-    if (first) bb = reduce_partials(pbb.a, pbb.na, pbb.b, pbb.nb, lds4);
+    if (first) bb = reduce_partials(pbb, lds4);
     else bb = S->bb;
     const bool go = check_tol ? (gamma / bb > tol2) : true;
     double beta = 0.0, alpha;
@@ -395,9 +402,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_finalize_kernel(part_ref pg, p
 {
     __shared__ double lds4[4];
     if (S->done) return;
-    double g = reduce_partials(pg.a, pg.na, pg.b, pg.nb, lds4);
-    double d = reduce_partials(pd.a, pd.na, pd.b, pd.nb, lds4);
-    double b = first ? reduce_partials(pb.a, pb.na, pb.b, pb.nb, lds4) : 0.0;
+    double g = reduce_partials(pg, lds4);
+    double d = reduce_partials(pd, lds4);
+    double b = first ? reduce_partials(pb, lds4) : 0.0;
     if (threadIdx.x == 0) { S->red[0] = g; S->red[1] = d; S->red[2] = b; }
 }
 
@@ -417,12 +424,12 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_pd), ((size_t)n + 2) * sizeof(double)));
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_s), ((size_t)n + 2) * sizeof(double)));
     }
-    part_ref pg_loc{m->d_part_b, vg, nullptr, 0};
-    part_ref pb_loc{m->d_part_c, vg, nullptr, 0};
-    part_ref pd_loc{m->d_part_a, kmcf_interior_grid(m), m->d_part_a + KMCF_MAX_PARTIALS, m->spmv_grid_b};
-    part_ref pg = multi ? part_ref{&S->red[0], 1, nullptr, 0} : pg_loc;
-    part_ref pd = multi ? part_ref{&S->red[1], 1, nullptr, 0} : pd_loc;
-    part_ref pb = multi ? part_ref{&S->red[2], 1, nullptr, 0} : pb_loc;
+    part_ref pg_loc = pr1(m->d_part_b, vg);
+    part_ref pb_loc = pr1(m->d_part_c, vg);
+    part_ref pd_loc = pr_spmv(m);
+    part_ref pg = multi ? pr1(&S->red[0], 1) : pg_loc;
+    part_ref pd = multi ? pr1(&S->red[1], 1) : pd_loc;
+    part_ref pb = multi ? pr1(&S->red[2], 1) : pb_loc;
 
     KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
@@ -461,7 +468,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
     }
     if (!done) {   // r.z after the last iteration, for the printed residual
         if (multi) {
-            cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg_loc, 0, part_ref{nullptr, 0, nullptr, 0}, -1, S, 1);
+            cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg_loc, 0, pr_none(), -1, S, 1);
             KMCF_HIP(hipGetLastError());
             KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 1));
         }

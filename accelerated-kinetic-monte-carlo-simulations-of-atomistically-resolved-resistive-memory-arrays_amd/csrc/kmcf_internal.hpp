@@ -98,10 +98,25 @@ struct kmcf_comm {
 };
 void kmcf_event_cache_free(kmcf_comm *c);
 
+struct kmcf_subop;   // sub-block operator of the split T matrix (kmcf_tstate.hip)
+
+constexpr int KMCF_LONG_CHUNK = 2048;    // entries of a long row handled by one block (spmv_long_kernel)
+
 struct kmcf_matrix {
     kmcf_comm *comm = nullptr;
     int matrix_size = 0;
     int n_loc = 0;
+    // Long rows (more than KMCF_LONG_ROW entries, default 384: the T matrix's two virtual-node rows hold
+    // one entry per contact atom of a layer, 578 at 5 nm and 33 602 at 40 nm) do not fit the tiles of the
+    // window / stream kernels.  They are moved to the END of the internal row order: the tiled kernels see
+    // rows [0, n_short), spmv_long_kernel handles rows [n_short, n_loc) in chunks of KMCF_LONG_CHUNK entries
+    // with a deterministic two-stage sum.  Vector kernels (CG updates) run over all n_loc rows.
+    int n_short = 0;
+    int n_long_items = 0;
+    int4 *d_long_items = nullptr;      // (row, first entry, end entry, first item of this row) per chunk
+    double *d_long_part = nullptr;     // one partial per chunk
+    unsigned int *d_long_ctr = nullptr;
+    kmcf_subop *sub = nullptr;         // optional: y[sub rows] += S x_sub after the CSR part (T matrix)
     int row0 = 0;                 // displs[rank]
     int64_t nnz = 0;
     std::vector<int> counts, displs;
@@ -145,7 +160,8 @@ struct kmcf_matrix {
     double *d_dinv = nullptr;
     double *d_pd = nullptr;            // single-reduction CG: search direction p (d_p then carries z)
     double *d_s = nullptr;             // single-reduction CG: s = A p by recurrence
-    double *d_part_a = nullptr;        // KMCF_MAX_PARTIALS x 2 (pAp partials)
+    double *d_part_a = nullptr;        // pAp partials: [0, MAXP) interior rows | [MAXP, 2 MAXP) boundary rows |
+                                       // [2 MAXP] long rows | [3 MAXP, 4 MAXP) sub-block operator
     double *d_part_b = nullptr;        // rz partials
     double *d_part_c = nullptr;        // bb partials
     kmcf_scalars *d_S = nullptr;
@@ -211,11 +227,35 @@ inline int kmcf_interior_grid(const kmcf_matrix *m)
     return (m->spmv_kind == 2 && m->coded) ? m->spmv_grid_coded : m->spmv_grid;
 }
 
+// Sub-block operator of a split matrix A = A_csr + P^T S P (the T matrix's tunnel block): S acts on the
+// sub-vector of the n_glob sub points of ALL ranks; this rank owns rows [displs[rank], +counts[rank]).
+// Stored as a bitmap over the n_glob columns (one 64-bit mask per 64 columns and row) plus the packed f64
+// values of the set positions: 8 B/nnz + 1 bit per position, against 12 B/nnz for CSR -- the block is
+// dense-ish (36 % at 5 nm here, 43 % in the authors' 40 nm test set, main_test_cg_split.cpp:1030-1035).
+struct kmcf_subop {
+    int n_glob = 0, n_loc = 0, row0 = 0;     // sub points: all ranks, this rank, first of this rank
+    int n_groups = 0;                        // ceil(n_glob / 64)
+    std::vector<int> counts, displs;
+    int *d_rows = nullptr;                   // internal local row of each local sub point
+    unsigned long long *d_mask = nullptr;    // n_loc x n_groups
+    long long *d_voff = nullptr;             // n_loc + 1: first value of each row
+    double *d_val = nullptr;
+    double *d_xsub = nullptr;                // n_glob: gathered sub-vector
+    long long nnz = 0;
+    size_t cap_mask = 0, cap_val = 0, cap_rows = 0, cap_x = 0, cap_voff = 0;
+    int grid = 0;                            // blocks of the operator kernel = partials it writes
+};
+
 // ---------------------------------------------------------------- internal entry points
 // spmv.hip
 int kmcf_spmv_plan(kmcf_matrix *m);
 // Ap = A*p on m->d_p (already holding local p), writes m->d_Ap and pAp partials.
 int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done);
+// the four p.Ap partial segments the last SpMV wrote (interior, boundary, long rows, sub-block)
+struct kmcf_part4 { const double *p[4]; int n[4]; };
+kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m);
+// tstate.hip: y[sub rows] += S x_sub (+ dot partials) on the compute stream; x_sub gathered from m->d_p
+int kmcf_subop_apply(kmcf_matrix *m, bool with_dot, bool skip_if_done);
 // Dictionary-code the values now in d_val (window kernel only; no-op otherwise).  h_dict/nd: the distinct
 // off-diagonal values; m->coded is set iff every off-diagonal value was found.  Synchronous.
 int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd);

@@ -170,28 +170,47 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         for (int s = 0; s < (int)m->cols_per_neighbour[k].size(); ++s)
             halo_gid[m->halo_offset[k] + s] = displs[m->neighbours[k]] + m->cols_per_neighbour[k][s];
 
-    // ---- optional internal row order: internal row i = caller row perm[i] -------------------
+    // ---- internal row order: internal row i = caller row perm[i] -----------------------------
+    // the caller's locality order (if any), then long rows moved behind all others (kmcf_internal.hpp)
     std::vector<int> rp(h_row_ptr, h_row_ptr + n_loc + 1);
     m->h_row_ptr_user = rp;
     std::vector<double> val_int;
     if (h_val) val_int.assign(h_val, h_val + nnz);
-    if (h_perm && n_loc > 0) {
+    std::vector<int> perm_eff;
+    if (h_perm && n_loc > 0) perm_eff.assign(h_perm, h_perm + n_loc);
+    int long_thr = 384;
+    if (const char *e = getenv("KMCF_LONG_ROW")) long_thr = atoi(e);
+    int n_long = 0;
+    if (long_thr > 0)
+        for (int r = 0; r < n_loc; ++r) n_long += (rp[r + 1] - rp[r] > long_thr);
+    if (n_long > 0) {
+        if (perm_eff.empty()) { perm_eff.resize((size_t)n_loc); for (int i = 0; i < n_loc; ++i) perm_eff[i] = i; }
+        for (int i = 0; i < n_loc; ++i)
+            if (perm_eff[i] < 0 || perm_eff[i] >= n_loc) {
+                kmcf_set_error("kmcf_matrix_build: perm is not a permutation of the local rows (entry %d = %d)", i, perm_eff[i]);
+                return KMCF_ERR_ARG;
+            }
+        std::stable_partition(perm_eff.begin(), perm_eff.end(), [&](int r) { return rp[r + 1] - rp[r] <= long_thr; });
+    }
+    m->n_short = n_loc - n_long;
+    if (!perm_eff.empty()) {
+        const int *hp = perm_eff.data();
         std::vector<int> inv((size_t)n_loc, -1);
         for (int i = 0; i < n_loc; ++i) {
-            const int r = h_perm[i];
+            const int r = hp[i];
             if (r < 0 || r >= n_loc || inv[r] != -1) {
                 kmcf_set_error("kmcf_matrix_build: perm is not a permutation of the local rows (entry %d = %d)", i, r);
                 return KMCF_ERR_ARG;
             }
             inv[r] = i;
         }
-        m->h_perm.assign(h_perm, h_perm + n_loc);
+        m->h_perm = perm_eff;
         std::vector<int> rp_new((size_t)n_loc + 1, 0), col_new((size_t)nnz);
         std::vector<double> val_new(h_val ? (size_t)nnz : 0);
         std::vector<unsigned char> isb_new((size_t)n_loc, 0);
-        for (int i = 0; i < n_loc; ++i) rp_new[i + 1] = rp_new[i] + (rp[h_perm[i] + 1] - rp[h_perm[i]]);
+        for (int i = 0; i < n_loc; ++i) rp_new[i + 1] = rp_new[i] + (rp[hp[i] + 1] - rp[hp[i]]);
         for (int i = 0; i < n_loc; ++i) {
-            const int r = h_perm[i];
+            const int r = hp[i];
             int dst = rp_new[i];
             for (int j = rp[r]; j < rp[r + 1]; ++j, ++dst) {
                 const int cl = col_local[j];
@@ -204,11 +223,21 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         col_local.swap(col_new);
         val_int.swap(val_new);
         is_boundary.swap(isb_new);
-        boundary_rows.clear();
-        for (int i = 0; i < n_loc; ++i)
-            if (is_boundary[i]) boundary_rows.push_back(i);
         for (int &s : send_idx) s = inv[s];                   // gather positions; packed order = protocol order
     }
+    // boundary pass = short rows that reference the halo (long rows wait for the halo in their own kernel)
+    boundary_rows.clear();
+    for (int i = 0; i < m->n_short; ++i)
+        if (is_boundary[i]) boundary_rows.push_back(i);
+    m->n_boundary_rows = (int)boundary_rows.size();
+    // chunks of the long rows
+    std::vector<int4> long_items;
+    for (int i = m->n_short; i < n_loc; ++i) {
+        const int first = (int)long_items.size();
+        for (int j = rp[i]; j < rp[i + 1]; j += KMCF_LONG_CHUNK)
+            long_items.push_back(make_int4(i, j, std::min(j + KMCF_LONG_CHUNK, rp[i + 1]), first));
+    }
+    m->n_long_items = (int)long_items.size();
     m->h_row_ptr = rp;
 
     if (c->device < 0) {  // host-only planning communicator: no device state
@@ -226,6 +255,11 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         KMCF_TRY(dev_alloc(&m->d_val, (size_t)nnz));
     }
     if (!m->h_perm.empty()) KMCF_TRY(dev_upload(&m->d_perm, m->h_perm));
+    if (m->n_long_items > 0) {
+        KMCF_TRY(dev_upload(&m->d_long_items, long_items));
+        KMCF_TRY(dev_alloc(&m->d_long_part, (size_t)m->n_long_items));
+        KMCF_TRY(dev_alloc(&m->d_long_ctr, 1));
+    }
     if (m->n_halo > 0) {
         KMCF_TRY(dev_upload(&m->d_is_boundary, is_boundary));
         KMCF_TRY(dev_upload(&m->d_boundary_rows, boundary_rows));
@@ -238,7 +272,7 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     KMCF_TRY(dev_alloc(&m->d_r, (size_t)n_loc + 2));
     KMCF_TRY(dev_alloc(&m->d_x, (size_t)n_loc + 2));
     KMCF_TRY(dev_alloc(&m->d_dinv, (size_t)n_loc + 2));
-    KMCF_TRY(dev_alloc(&m->d_part_a, (size_t)2 * KMCF_MAX_PARTIALS));
+    KMCF_TRY(dev_alloc(&m->d_part_a, (size_t)4 * KMCF_MAX_PARTIALS));
     KMCF_TRY(dev_alloc(&m->d_part_b, (size_t)KMCF_MAX_PARTIALS));
     KMCF_TRY(dev_alloc(&m->d_part_c, (size_t)KMCF_MAX_PARTIALS));
     KMCF_TRY(dev_alloc(&m->d_S, 1));
@@ -248,7 +282,7 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     if (h_val) {
         long long dict[KMCF_DICT_MAX];
         int nd = 0, last = -1;
-        for (int i = 0; i < n_loc && m->expect_coded; ++i)
+        for (int i = 0; i < m->n_short && m->expect_coded; ++i)
             for (int j = rp[i]; j < rp[i + 1]; ++j) {
                 if (col_local[j] == i) continue;
                 long long b;
@@ -332,7 +366,8 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,
-                        m->d_tile, m->d_wcol, m->d_idx16, m->d_dict, m->d_diagv, m->d_diag_pos, m->d_code_fail};
+                        m->d_tile, m->d_wcol, m->d_idx16, m->d_dict, m->d_diagv, m->d_diag_pos, m->d_code_fail,
+                        m->d_long_items, m->d_long_part, m->d_long_ctr};
         for (void *p : ptrs)
             if (p) hipFree(p);
     }

@@ -393,6 +393,48 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_kernel(
     }
 }
 
+// ------------------------------------------------------------------ long rows
+// Rows [n_short, n_loc): one block per chunk of KMCF_LONG_CHUNK entries; the last block to finish (atomic
+// counter) adds each row's chunk sums in chunk order and writes y -- deterministic, one launch.  Values always
+// come from val (long rows are never dictionary-coded).
+template <bool DOT>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_long_kernel(
+    int n_items, const int4 *__restrict__ items, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ lpart, unsigned int *__restrict__ ctr,
+    double *__restrict__ part, const kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double lds4[4];
+    __shared__ int s_last;
+    if (check_done && S->done) return;
+    const int4 it = items[blockIdx.x];
+    double s = 0.0;
+    for (int j = it.y + threadIdx.x; j < it.z; j += KMCF_BLOCK) s += val[j] * x[col[j]];
+    s = block_sum_256(s, lds4);
+    if (threadIdx.x == 0) {
+        lpart[blockIdx.x] = s;
+        __threadfence();
+        s_last = (atomicAdd(ctr, 1u) == (unsigned int)(n_items - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double dot = 0.0;
+    for (int q = threadIdx.x; q < n_items; q += KMCF_BLOCK) {
+        const int4 a = items[q];
+        if (a.w != q) continue;                              // first chunk of its row: this thread sums the row
+        double t = 0.0;
+        for (int c = q; c < n_items && items[c].x == a.x; ++c)
+            t += __hip_atomic_load(lpart + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by other blocks
+        y[a.x] = t;
+        if (DOT) dot += x[a.x] * t;
+    }
+    if (DOT) {
+        const double t = block_sum_256(dot, lds4);
+        if (threadIdx.x == 0) part[0] = t;
+    }
+    if (threadIdx.x == 0) *ctr = 0u;
+}
+
 __global__ __launch_bounds__(KMCF_BLOCK) void pack_kernel(double *__restrict__ packed, const double *__restrict__ src,
                                                           const int *__restrict__ idx, int n,
                                                           const kmcf_scalars *__restrict__ S, int check_done)
@@ -444,14 +486,14 @@ void launch_vec(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool boundary_
         const bool skipb = (m->n_halo > 0);
         if (with_dot) {
             if (skipb)
-                spmv_vec_kernel<LPR, true, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, m->d_is_boundary, nullptr, m->d_part_a));
+                spmv_vec_kernel<LPR, true, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_short, m->d_is_boundary, nullptr, m->d_part_a));
             else
-                spmv_vec_kernel<LPR, true, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, nullptr, nullptr, m->d_part_a));
+                spmv_vec_kernel<LPR, true, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_short, nullptr, nullptr, m->d_part_a));
         } else {
             if (skipb)
-                spmv_vec_kernel<LPR, false, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, m->d_is_boundary, nullptr, nullptr));
+                spmv_vec_kernel<LPR, false, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_short, m->d_is_boundary, nullptr, nullptr));
             else
-                spmv_vec_kernel<LPR, false, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_loc, nullptr, nullptr, nullptr));
+                spmv_vec_kernel<LPR, false, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_VEC_ARGS(m->n_short, nullptr, nullptr, nullptr));
         }
     } else {
         const int grid = m->spmv_grid_b;
@@ -600,9 +642,9 @@ int env_int(const char *name, int dflt)
 int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 {
     *ok = false;
-    const int n = m->n_loc;
-    if (n == 0 || m->nnz == 0) return KMCF_OK;
+    const int n = m->n_short;                        // long rows have their own kernel
     const std::vector<int> &rp = m->h_row_ptr;
+    if (n == 0 || rp[n] == 0) return KMCF_OK;
     // the row limit serves the coded kernel (full passes of its row lanes); the plain kernel, whose cost is
     // the value stream, prefers tiles filled to the entry limit
     const char *ce = getenv("KMCF_SPMV_CODED");
@@ -642,10 +684,10 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     }
     tiles.push_back(make_int2(n, (int)wcol.size()));
     const int nt = (int)tiles.size() - 1;
-    if (judge && double(m->nnz) < 2.0 * double(wcol.size())) return KMCF_OK;
+    if (judge && double(rp[n]) < 2.0 * double(wcol.size())) return KMCF_OK;
     if (getenv("KMCF_SPMV_VERBOSE"))
         fprintf(stderr, "kmcf window plan: %d tiles, %.1f rows, %.1f nnz, %.1f window columns per tile\n", nt, double(n) / nt,
-                double(m->nnz) / nt, double(wcol.size()) / nt);
+                double(rp[n]) / nt, double(wcol.size()) / nt);
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tile), tiles.size() * sizeof(int2)));
     wcol.push_back(0);                                    // spare elements: wcode_issue_loads clamps, never branches
     idx.resize(idx.size() + KMCF_BLOCK * 16 + 16, 0);    // the coded kernel's block-wide slot load may run past the last tile
@@ -710,7 +752,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void encode_values_kernel(int n, const 
 int kmcf_spmv_plan(kmcf_matrix *m)
 {
     // vec kernel: lanes per row from the mean row length (K rows hold 4..53 entries, mean 25.8)
-    const double mean = m->n_loc > 0 ? double(m->nnz) / m->n_loc : 0.0;
+    const double mean = m->n_short > 0 ? double(m->h_row_ptr[m->n_short]) / m->n_short : 0.0;
     int lpr = 4;
     while (lpr < 64 && lpr * 2 <= mean) lpr *= 2;  // 25.8 -> 16
     {
@@ -751,15 +793,15 @@ int kmcf_spmv_plan(kmcf_matrix *m)
         const std::vector<int> &rp = m->h_row_ptr;
         chunk_row.push_back(0);
         int r = 0;
-        while (r < m->n_loc) {
+        while (r < m->n_short) {
             const int start = rp[r];
             int e = r;
-            while (e < m->n_loc && rp[e + 1] - start <= cap) ++e;
+            while (e < m->n_short && rp[e + 1] - start <= cap) ++e;
             if (e == r) { kind = 0; break; }   // a single row exceeds a chunk: vector kernel
             chunk_row.push_back(e);
             r = e;
         }
-        if (m->n_loc == 0) kind = 0;
+        if (m->n_short == 0) kind = 0;
     }
     m->spmv_kind = kind;
     if (kind == 1) {
@@ -768,7 +810,7 @@ int kmcf_spmv_plan(kmcf_matrix *m)
         KMCF_HIP(hipMemcpy(m->d_chunk_row, chunk_row.data(), chunk_row.size() * sizeof(int), hipMemcpyHostToDevice));
         m->spmv_grid = grid_for(m->n_chunks, 1);
     } else {
-        m->spmv_grid = grid_for(m->n_loc, KMCF_BLOCK / lpr);
+        m->spmv_grid = grid_for(m->n_short, KMCF_BLOCK / lpr);
     }
     return KMCF_OK;
 }
@@ -803,14 +845,14 @@ int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
 int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd)
 {
     m->coded = false;
-    if (!coding_enabled(m) || m->n_loc == 0) return KMCF_OK;
+    if (!coding_enabled(m) || m->n_short == 0) return KMCF_OK;
     hipStream_t st = m->comm->stream;
     KMCF_TRY(kmcf_matrix_set_dictionary(m, h_dict, nd));
     m->coded = false;
     KMCF_HIP(hipMemsetAsync(m->d_code_fail, 0, sizeof(int), st));
     constexpr int LPR = 16;
-    encode_values_kernel<LPR><<<grid_for(m->n_loc, KMCF_BLOCK / LPR), KMCF_BLOCK, 0, st>>>(
-        m->n_loc, m->d_row_ptr, m->d_diag_pos, m->d_val, m->d_dict, nd, m->d_idx16, m->d_diagv, m->d_code_fail);
+    encode_values_kernel<LPR><<<grid_for(m->n_short, KMCF_BLOCK / LPR), KMCF_BLOCK, 0, st>>>(
+        m->n_short, m->d_row_ptr, m->d_diag_pos, m->d_val, m->d_dict, nd, m->d_idx16, m->d_diagv, m->d_code_fail);
     KMCF_HIP(hipGetLastError());
     int fail = 1;
     KMCF_HIP(hipMemcpyAsync(&fail, m->d_code_fail, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -822,13 +864,13 @@ int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd)
 int kmcf_matrix_encode_from_host(kmcf_matrix *m, const double *h_val_internal)
 {
     m->coded = false;
-    if (!coding_enabled(m) || m->n_loc == 0) return KMCF_OK;
+    if (!coding_enabled(m) || m->n_short == 0) return KMCF_OK;
     // distinct off-diagonal values (bit patterns); give up at the first one beyond the dictionary size
     long long dict[KMCF_DICT_MAX];
     int nd = 0;
     const std::vector<int> &rp = m->h_row_ptr;
     int last = -1;
-    for (int i = 0; i < m->n_loc; ++i) {
+    for (int i = 0; i < m->n_short; ++i) {
         const int dp = m->h_diag_pos[i];
         for (int j = rp[i]; j < rp[i + 1]; ++j) {
             if (j == dp) continue;
@@ -889,7 +931,30 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done)
             KMCF_HIP(hipGetLastError());
         }
     }
+    if (m->n_long_items > 0) {
+        hipStream_t st = m->comm->stream;
+        const int chk = skip_if_done ? 1 : 0;
+        double *part = m->d_part_a + 2 * KMCF_MAX_PARTIALS;
+        if (with_dot)
+            spmv_long_kernel<true><<<m->n_long_items, KMCF_BLOCK, 0, st>>>(m->n_long_items, m->d_long_items, m->d_col, m->d_val, m->d_p,
+                                                                          m->d_Ap, m->d_long_part, m->d_long_ctr, part, m->d_S, chk);
+        else
+            spmv_long_kernel<false><<<m->n_long_items, KMCF_BLOCK, 0, st>>>(m->n_long_items, m->d_long_items, m->d_col, m->d_val, m->d_p,
+                                                                           m->d_Ap, m->d_long_part, m->d_long_ctr, part, m->d_S, chk);
+        KMCF_HIP(hipGetLastError());
+    }
+    if (m->sub) KMCF_TRY(kmcf_subop_apply(m, with_dot, skip_if_done));
     return KMCF_OK;
+}
+
+kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m)
+{
+    kmcf_part4 q;
+    q.p[0] = m->d_part_a;                           q.n[0] = kmcf_interior_grid(m);
+    q.p[1] = m->d_part_a + KMCF_MAX_PARTIALS;       q.n[1] = m->n_halo > 0 ? m->spmv_grid_b : 0;
+    q.p[2] = m->d_part_a + 2 * KMCF_MAX_PARTIALS;   q.n[2] = m->n_long_items > 0 ? 1 : 0;
+    q.p[3] = m->d_part_a + 3 * KMCF_MAX_PARTIALS;   q.n[3] = m->sub ? m->sub->grid : 0;
+    return q;
 }
 
 extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)

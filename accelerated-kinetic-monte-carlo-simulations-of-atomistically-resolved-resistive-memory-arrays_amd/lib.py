@@ -24,6 +24,20 @@ class MatrixInfo(C.Structure):
                 ("spmv_window_cols", C.c_int64)]
 
 
+class TStateInfo(C.Structure):
+    _fields_ = [("N_atom", C.c_int), ("Nsub", C.c_int), ("rows_this_rank", C.c_int), ("nnz_neighbour", C.c_int64),
+                ("tunnel_points", C.c_int), ("tunnel_points_rank", C.c_int), ("tunnel_first", C.c_int),
+                ("nnz_tunnel", C.c_int64)]
+
+
+class CurrentParams(C.Structure):
+    """kmcf_current_params_t"""
+    _fields_ = [("Vd", C.c_double), ("high_G", C.c_double), ("low_G", C.c_double), ("loop_G", C.c_double),
+                ("G0", C.c_double), ("tol", C.c_double), ("m_e", C.c_double), ("V0", C.c_double),
+                ("alpha_disp", C.c_double), ("contact_x_lo", C.c_double), ("contact_x_hi", C.c_double),
+                ("cg_tolerance", C.c_double), ("cg_max_iterations", C.c_int), ("solve_heating", C.c_int)]
+
+
 class SolveStats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("relres", C.c_double), ("bb", C.c_double),
                 ("rz", C.c_double), ("ms_solve", C.c_float), ("ms_assembly", C.c_float)]
@@ -82,6 +96,18 @@ SIGNATURES = {
     "kmcf_compute_cutoff_list": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.POINTER(_P)]),
     "kmcf_pairwise_destroy": (C.c_int, [_P]),
     "kmcf_poisson_gridless": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_int, C.c_int, _P]),
+    "kmcf_initialize_sparsity_T": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _IP, _IP,
+                                             C.POINTER(_P)]),
+    "kmcf_tstate_destroy": (C.c_int, [_P]),
+    "kmcf_tstate_matrix": (_P, [_P]),
+    "kmcf_tstate_info": (C.c_int, [_P, C.POINTER(TStateInfo)]),
+    "kmcf_tstate_pattern": (C.c_int, [_P, _IP, _IP, C.POINTER(C.c_int64)]),
+    "kmcf_tstate_atom_sites": (C.c_int, [_P, _IP]),
+    "kmcf_tstate_get_vectors": (C.c_int, [_P, _DP, _DP, _DP]),
+    "kmcf_tstate_get_tunnel": (C.c_int, [_P, _IP, _IP, _IP, _DP, _DP]),
+    "kmcf_t_assemble": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(CurrentParams)]),
+    "kmcf_update_power_sparse": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, C.POINTER(CurrentParams),
+                                           C.POINTER(C.c_double), C.POINTER(SolveStats)]),
     "kmcf_update_temperature_global": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_double, C.c_double]),
     "kmcf_rng_create": (C.c_int, [C.c_uint, C.POINTER(_P)]),

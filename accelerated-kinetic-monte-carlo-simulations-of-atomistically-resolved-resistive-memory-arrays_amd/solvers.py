@@ -41,6 +41,8 @@ class KMC_comm:
         self.rank_K = self.rank_events = self.rank_pairwise = rank
         self.size_K = self.size_events = self.size_pairwise = size
         self.counts_K, self.displs_K = self.partition(nrows_K, size)
+        self.rank_T, self.size_T = rank, size                      # the reference forces comm_T off (KMC_comm.h:243)
+        self.counts_T, self.displs_T = self.partition(nrows_T, size)
         self.counts_pairwise, self.displs_pairwise = self.partition(nrows_pairwise, size)
         self.counts_events, self.displs_events = self.partition(nrows_events, size)
         self.device = device
@@ -125,8 +127,15 @@ class GPUBuffers:
         self.neigh_idx = None
         self.cutoff_idx = None         # kmcf_pairwise* (replaces cutoff_idx / cutoff_window)
         self.K_distributed = None      # kmcf_kstate* (K_distributed + K_p_distributed + contact patterns)
+        self.T_distributed = None      # kmcf_tstate* (T_distributed + T_p_distributed + atom_* arrays)
+        self.site_CB_edge = None
+        self.atom_virtual_potentials = None   # N_atom + 2 doubles, allocated by initialize_sparsity_T
+        self.N_atom_ = 0
 
     def freeGPUmemory(self):
+        if self.T_distributed is not None:
+            _L.load().kmcf_tstate_destroy(self.T_distributed)
+            self.T_distributed = None
         if self.K_distributed is not None:
             _L.load().kmcf_kstate_destroy(self.K_distributed)
             self.K_distributed = None
@@ -200,6 +209,127 @@ def update_CB_edge_gpu_sparse(gpubuf, N, N_left_tot, N_right_tot, Vd, pbc, high_
                                             int(N), int(N_left_tot), int(N_right_tot), float(Vd), float(high_G),
                                             float(low_G), C.byref(st)), "kmcf_update_CB_edge_sparse")
     return st.as_dict()
+
+
+def initialize_sparsity_T(gpubuf, pbc, nn_dist, num_source_inj, num_ground_ext, num_layers_contact, kmc_comm):
+    """initialize_sparsity_T (gpu_solvers.h:57; src/initialize_sparsity_T.cu:948-1154).  kmc_comm.counts_T must
+    partition N_atom + 1 rows (src/kmc_main.cpp:165-171); pbc is accepted and, like the reference's T kernels,
+    not used (they call the non-periodic site_dist_gpu overload)."""
+    lib = _L.load()
+    if gpubuf.T_distributed is not None:
+        lib.kmcf_tstate_destroy(gpubuf.T_distributed)
+        gpubuf.T_distributed = None
+    h = C.c_void_p()
+    cnt, cntp = _ia(kmc_comm.counts_T)
+    dsp, dspp = _ia(kmc_comm.displs_T)
+    _L.check(lib.kmcf_initialize_sparsity_T(kmc_comm.handle, _ptr(gpubuf.site_x), _ptr(gpubuf.site_y), _ptr(gpubuf.site_z),
+                                            _ptr(gpubuf.site_element), gpubuf.N_, float(nn_dist), int(num_source_inj),
+                                            int(num_ground_ext), int(num_layers_contact), cntp, dspp, C.byref(h)),
+             "kmcf_initialize_sparsity_T")
+    gpubuf.T_distributed = h
+    info = t_info(gpubuf)
+    gpubuf.N_atom_ = info["N_atom"]
+    if gpubuf.atom_virtual_potentials is None or gpubuf.atom_virtual_potentials.numel() != info["N_atom"] + 2:
+        gpubuf.atom_virtual_potentials = torch.zeros(info["N_atom"] + 2, dtype=torch.float64, device=gpubuf.device)
+
+
+def current_params(Vd, high_G, low_G, loop_G, G0, tol, m_e, V0, alpha_disp=1.0, solve_heating=False,
+                   cg_tolerance=None, cg_max_iterations=100, N_atom=None, contact_x_lo=-4.2, contact_x_hi=52.65):
+    """kmcf_current_params_t.  Defaults = what the reference hard-codes: cg tolerance 1e-30 * N_atom and 100
+    iterations (src/current_solver_gpu.cu:1455-1456), contact window -4.2 .. 52.65 A (initialize_sparsity_T.cu:645)."""
+    if cg_tolerance is None:
+        cg_tolerance = 1e-30 * (N_atom or 1)
+    return _L.CurrentParams(float(Vd), float(high_G), float(low_G), float(loop_G), float(G0), float(tol), float(m_e),
+                            float(V0), float(alpha_disp), float(contact_x_lo), float(contact_x_hi), float(cg_tolerance),
+                            int(cg_max_iterations), int(bool(solve_heating)))
+
+
+def t_assemble(gpubuf, params):
+    """Assembly half of update_power_gpu_sparse_dist (src/current_solver_gpu.cu:1496-1632)."""
+    _L.check(_L.load().kmcf_t_assemble(gpubuf.T_distributed, _ptr(gpubuf.site_element), _ptr(gpubuf.site_charge),
+                                       _ptr(gpubuf.site_CB_edge), _ptr(gpubuf.metal_types), gpubuf.num_metal_types_,
+                                       C.byref(params)), "kmcf_t_assemble")
+
+
+def update_power_gpu_sparse_dist(gpubuf, num_source_inj, num_ground_ext, num_layers_contact, Vd, high_G, low_G, loop_G,
+                                 G0, tol, nn_dist, m_e, V0, num_metals, solve_heating_local, solve_heating_global,
+                                 alpha_disp, cg_tolerance=None, cg_max_iterations=100, contact_x_lo=-4.2,
+                                 contact_x_hi=52.65):
+    """update_power_gpu_sparse_dist (gpu_solvers.h:212; src/current_solver_gpu.cu:1430-1855).  Returns
+    (imacro, solve statistics); gpubuf.atom_virtual_potentials and gpubuf.site_power are updated in place."""
+    lib = _L.load()
+    prm = current_params(Vd, high_G, low_G, loop_G, G0, tol, m_e, V0, alpha_disp,
+                         bool(solve_heating_local or solve_heating_global), cg_tolerance, cg_max_iterations,
+                         gpubuf.N_atom_, contact_x_lo, contact_x_hi)
+    st = _L.SolveStats()
+    im = C.c_double(0.0)
+    _L.check(lib.kmcf_update_power_sparse(gpubuf.T_distributed, _ptr(gpubuf.site_element), _ptr(gpubuf.site_charge),
+                                          _ptr(gpubuf.site_CB_edge), _ptr(gpubuf.metal_types), int(num_metals),
+                                          _ptr(gpubuf.atom_virtual_potentials), _ptr(gpubuf.site_power), C.byref(prm),
+                                          C.byref(im), C.byref(st)), "kmcf_update_power_sparse")
+    return im.value, st.as_dict()
+
+
+def t_info(gpubuf):
+    info = _L.TStateInfo()
+    _L.check(_L.load().kmcf_tstate_info(gpubuf.T_distributed, C.byref(info)), "kmcf_tstate_info")
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def t_pattern(gpubuf):
+    """(row_ptr, col) of this rank's rows of the T neighbour matrix, global columns."""
+    lib = _L.load()
+    n = t_info(gpubuf)["rows_this_rank"]
+    nnz = C.c_int64()
+    rp = np.zeros(n + 1, np.int32)
+    _L.check(lib.kmcf_tstate_pattern(gpubuf.T_distributed, rp.ctypes.data_as(C.POINTER(C.c_int)), None, C.byref(nnz)),
+             "kmcf_tstate_pattern")
+    col = np.zeros(max(nnz.value, 1), np.int32)
+    _L.check(lib.kmcf_tstate_pattern(gpubuf.T_distributed, rp.ctypes.data_as(C.POINTER(C.c_int)),
+                                     col.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nnz)), "kmcf_tstate_pattern")
+    return rp, col[:nnz.value]
+
+
+def t_atom_sites(gpubuf):
+    a = np.zeros(t_info(gpubuf)["N_atom"], np.int32)
+    _L.check(_L.load().kmcf_tstate_atom_sites(gpubuf.T_distributed, a.ctypes.data_as(C.POINTER(C.c_int))),
+             "kmcf_tstate_atom_sites")
+    return a
+
+
+def t_vectors(gpubuf):
+    """After t_assemble: dict(val, diag_neighbour, dinv, rhs) of this rank's rows (caller order)."""
+    lib = _L.load()
+    info = t_info(gpubuf)
+    n = info["rows_this_rank"]
+    out = {k: np.zeros(max(n, 1)) for k in ("diag_neighbour", "dinv", "rhs")}
+    dp = C.POINTER(C.c_double)
+    _L.check(lib.kmcf_tstate_get_vectors(gpubuf.T_distributed, out["diag_neighbour"].ctypes.data_as(dp),
+                                         out["dinv"].ctypes.data_as(dp), out["rhs"].ctypes.data_as(dp)),
+             "kmcf_tstate_get_vectors")
+    out = {k: v[:n] for k, v in out.items()}
+    val = np.zeros(max(info["nnz_neighbour"], 1))
+    _L.check(lib.kmcf_matrix_get_values(lib.kmcf_tstate_matrix(gpubuf.T_distributed), val.ctypes.data_as(dp)),
+             "kmcf_matrix_get_values")
+    out["val"] = val[:info["nnz_neighbour"]]
+    return out
+
+
+def t_tunnel(gpubuf):
+    """After t_assemble: dict(tunnel_idx, row_ptr, col, val, diag) of this rank's rows of the tunnel sub-block."""
+    lib = _L.load()
+    info = t_info(gpubuf)
+    nt, ns, nnz = info["tunnel_points"], info["tunnel_points_rank"], info["nnz_tunnel"]
+    tidx = np.zeros(max(nt, 1), np.int32)
+    rp = np.zeros(ns + 1, np.int32)
+    col = np.zeros(max(nnz, 1), np.int32)
+    val = np.zeros(max(nnz, 1))
+    diag = np.zeros(max(ns, 1))
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    _L.check(lib.kmcf_tstate_get_tunnel(gpubuf.T_distributed, tidx.ctypes.data_as(ip), rp.ctypes.data_as(ip),
+                                        col.ctypes.data_as(ip), val.ctypes.data_as(dp), diag.ctypes.data_as(dp)),
+             "kmcf_tstate_get_tunnel")
+    return dict(tunnel_idx=tidx[:nt], row_ptr=rp, col=col[:nnz], val=val[:nnz], diag=diag[:ns], first=info["tunnel_first"])
 
 
 def sum_and_gather_potential(gpubuf, num_atoms_first_layer, kmc_comm):

@@ -298,6 +298,92 @@ int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, const int *h_
                           double (*next_random)(void *), void *rng_user, int max_events,
                           double *event_time, int *n_events, int *h_event_log);
 
+/* ---------------------------------------------------------------------- */
+/* T path: current solve (Kirchhoff matrix with two virtual nodes + WKB       */
+/* tunnelling sub-block), SURVEY 8 rows a14 / f3.  PARITY UNPINNED: no         */
+/* reference fixture exercises it (src/KMC_comm.h:243 disables it from main).  */
+/* ---------------------------------------------------------------------- */
+typedef struct kmcf_tstate kmcf_tstate; /* gpubuf.T_distributed + T_p_distributed + the atom_* arrays */
+
+/* initialize_sparsity_T (src/initialize_sparsity_T.cu:948-1154), called once per bias point
+ * (src/kmc_main.cpp:273): filters the sites into atoms (element != DEFECT, OXYGEN_DEFECT;
+ * update_atom_arrays, src/current_solver_gpu.cu:1341-1365 -- the set is invariant under KMC
+ * events, which only turn O <-> V and d <-> Od) and builds the pattern of the neighbour matrix
+ * over Nsub = N_atom + 1 nodes (0 = extraction, 1 = injection, 2.. = atoms, the last atom --
+ * the ground node -- cut) for the rows [displs[rank], +counts[rank]) of counts_T / displs_T
+ * (kmc_comm.counts_T).  Cell list instead of the O(n_loc * Nsub) scans; the distance is the
+ * non-periodic one the reference's T kernels use whatever pbc says (src/gpu_solvers.h:280-285). */
+int kmcf_initialize_sparsity_T(kmcf_comm *c, const double *d_site_x, const double *d_site_y,
+                               const double *d_site_z, const int *d_site_element, int N, double nn_dist,
+                               int num_source_inj, int num_ground_ext, int num_layers_contact,
+                               const int *h_counts_T, const int *h_displs_T, kmcf_tstate **out);
+int kmcf_tstate_destroy(kmcf_tstate *t);
+kmcf_matrix *kmcf_tstate_matrix(kmcf_tstate *t);   /* gpubuf.T_distributed (neighbour part) */
+
+typedef struct {
+    int N_atom;             /* gpubuf.N_atom_                                        */
+    int Nsub;               /* matrix size = N_atom + 1                              */
+    int rows_this_rank;
+    int64_t nnz_neighbour;  /* this rank                                             */
+    int tunnel_points;      /* all ranks (num_tunnel_points_global)                  */
+    int tunnel_points_rank; /* counts_subblock[rank]                                 */
+    int tunnel_first;       /* displ_subblock[rank]                                  */
+    int64_t nnz_tunnel;     /* this rank's rows of the tunnel sub-block              */
+} kmcf_tstate_info_t;
+int kmcf_tstate_info(const kmcf_tstate *t, kmcf_tstate_info_t *info);
+/* Exports for tests / inspection.  Pattern: rows of this rank, GLOBAL columns ascending (pass
+ * h_col = NULL to query *nnz).  atom_site: site index of every atom (N_atom ints). */
+int kmcf_tstate_pattern(const kmcf_tstate *t, int *h_row_ptr, int *h_col, int64_t *nnz);
+int kmcf_tstate_atom_sites(const kmcf_tstate *t, int *h_atom_site);
+/* After kmcf_t_assemble: per-row vectors of this rank (caller row order; NULL to skip):
+ * diagonal of the neighbour part, 1/diagonal of the whole operator (the preconditioner), rhs. */
+int kmcf_tstate_get_vectors(const kmcf_tstate *t, double *h_diag_neighbour, double *h_dinv, double *h_rhs);
+/* After kmcf_t_assemble: the tunnel sub-block of this rank as CSR (columns = global tunnel
+ * point ids, ascending; sizes from kmcf_tstate_info): h_tunnel_idx (all tunnel_points atom
+ * indices), h_row_ptr (tunnel_points_rank + 1), h_col / h_val (nnz_tunnel), h_diag
+ * (tunnel_points_rank).  Any pointer may be NULL. */
+int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, int *h_row_ptr, int *h_col, double *h_val,
+                           double *h_diag);
+
+typedef struct {
+    double Vd;
+    double high_G, low_G, loop_G;  /* src/kmc_main.cpp:294-296: 1e5*p.high_G, p.low_G, 1e7*p.high_G */
+    double G0;                     /* :298                                                        */
+    double tol;                    /* [J] barrier-slope tolerance, p.q * 0.01 (:299)              */
+    double m_e, V0;                /* effective mass [kg], defect state energy [eV]               */
+    double alpha_disp;             /* fraction of the power dissipated as heat (:302)            */
+    double contact_x_lo, contact_x_hi;  /* Ti / N atoms with x in this window are tunnel points; the
+                                      reference hard-codes -4.2 and 52.65 (initialize_sparsity_T.cu:645) */
+    double cg_tolerance;           /* the reference passes 1e-30 * N_atom (current_solver_gpu.cu:1455),
+                                      i.e. "run max_iterations"; its commented value is 1e-15 * N_atom */
+    int cg_max_iterations;         /* 100 there (:1456)                                           */
+    int solve_heating;             /* solve_heating_local || solve_heating_global                */
+} kmcf_current_params_t;
+
+/* Assembly half of update_power_gpu_sparse_dist (src/current_solver_gpu.cu:1496-1632): atom
+ * arrays, neighbour values + diagonal (populate_T_dist :1051-1247, calc_diagonal_T /
+ * insert_diag_T :1279-1321), tunnel sub-block pattern + WKB values + diagonal
+ * (assemble_sparse_T_submatrix, src/initialize_sparsity_T.cu:707-946), preconditioner
+ * (:1323-1338) and right-hand side (:1627-1632).  d_site_CB_edge: update_CB_edge's output [J]. */
+int kmcf_t_assemble(kmcf_tstate *t, const int *d_site_element, const int *d_site_charge,
+                    const double *d_site_CB_edge, const int *d_metals, int num_metals,
+                    const kmcf_current_params_t *p);
+
+/* update_power_gpu_sparse_dist (src/current_solver_gpu.cu:1430-1855; gpu_solvers.h:212):
+ * assembly, conjugate_gradient_jacobi_split_sparse (dist_iterative/
+ * dist_conjugate_gradient_split_sparse.cpp:18-182) started from d_atom_virtual_potentials
+ * (N_atom + 2 doubles, gpubuf.atom_virtual_potentials) and solved in place, then -- what the
+ * reference has behind its benchmark exit(1), restated from update_power_gpu_sparse
+ * (:2035-2160) -- the potentials are gathered on every rank and scaled by G0 in place,
+ * *imacro = injected current (get_imacro_sparse :501-542), and with solve_heating the
+ * potentials are shifted by |min| in place and d_site_power (N doubles) receives
+ * -alpha * P of every non-metal atom (semantics of the dense kernels set_ineg / copy_pdisp,
+ * :2353-2379, :462-474; DESIGN.md records why set_ineg_sparse is not followed). */
+int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_element, const int *d_site_charge,
+                             const double *d_site_CB_edge, const int *d_metals, int num_metals,
+                             double *d_atom_virtual_potentials, double *d_site_power,
+                             const kmcf_current_params_t *p, double *imacro, kmcf_solve_stats_t *stats);
+
 /* update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70). */
 int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,
                                    double a_coeff, double b_coeff, double number_steps,

@@ -1,0 +1,285 @@
+"""GPU: the T path (current solve: Kirchhoff neighbour matrix with two virtual nodes + WKB tunnel sub-block,
+split-operator Jacobi-PCG, I_macro, dissipated power) through the C ABI against oracle/kmcf_oracle_T.c.
+
+PARITY UNPINNED: no reference fixture covers this path (tests/test_oracle_T.py says what pins the oracle).
+Bars: integer work (atom list, both patterns, tunnel points) bit-exact; neighbour off-diagonals bit-exact,
+diagonals / preconditioner rtol 1e-13; WKB values rtol 1e-10 (device exp/pow against glibc's through an exponent
+of magnitude ~30); SpMV |dy| <= 1e-12 sum|a||x|; PCG at equal iteration count max|dx| <= 1e-9 |x|max; I_macro
+1e-9 relative; power 1e-8 of its maximum."""
+import threading
+
+import numpy as np
+import pytest
+
+from test_oracle_T import PAR, Q, TI, N_EL, small_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+G0 = 2 * 3.8612e-5 * 1e-5
+
+
+def _make(km, torch, xyz, element, charge, cb, metals, n1, layers, comm, nn_dist=3.5):
+    S = km.solvers
+    N = len(element)
+    buf = S.GPUBuffers(N, element, xyz[:, 0], xyz[:, 1], xyz[:, 2], 52, 3.5e-10, 1.0, [1, 1, 1], metals)
+    buf.site_charge.copy_(torch.as_tensor(np.asarray(charge, np.int32)))
+    buf.site_CB_edge = torch.as_tensor(np.asarray(cb, np.float64), device="cuda")
+    S.initialize_sparsity_T(buf, 0, nn_dist, n1, n1, layers, comm)
+    return buf
+
+
+def _compare_assembly(S, buf, T, r0=0, nr=None, s_first=None):
+    nr = T.Nsub if nr is None else nr
+    rp, col = S.t_pattern(buf)
+    want_rp = T.row_ptr[r0:r0 + nr + 1] - T.row_ptr[r0]
+    np.testing.assert_array_equal(rp, want_rp)
+    sl = slice(T.row_ptr[r0], T.row_ptr[r0 + nr])
+    np.testing.assert_array_equal(col, T.col[sl])
+    v = S.t_vectors(buf)
+    rows = np.repeat(np.arange(r0, r0 + nr), np.diff(want_rp))
+    offd = T.col[sl] != rows
+    np.testing.assert_array_equal(v["val"][offd], T.val[sl][offd])                  # -high_G / -low_G / -loop_G
+    np.testing.assert_allclose(v["val"][~offd], T.val[sl][~offd], rtol=1e-13)
+    np.testing.assert_allclose(v["diag_neighbour"], T.diag_neigh[r0:r0 + nr], rtol=1e-13)
+    np.testing.assert_array_equal(v["rhs"], T.rhs[r0:r0 + nr])
+    tn = S.t_tunnel(buf)
+    np.testing.assert_array_equal(tn["tunnel_idx"], T.tunnel_idx)
+    s0 = tn["first"]
+    ns = len(tn["row_ptr"]) - 1
+    np.testing.assert_array_equal(tn["row_ptr"], T.sub_row_ptr[s0:s0 + ns + 1] - T.sub_row_ptr[s0])
+    ssl = slice(T.sub_row_ptr[s0], T.sub_row_ptr[s0 + ns])
+    np.testing.assert_array_equal(tn["col"], T.sub_col[ssl])
+    np.testing.assert_allclose(tn["val"], T.sub_val[ssl], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(tn["diag"], T.diag_tunnel[s0:s0 + ns], rtol=1e-10)
+    # preconditioner of the whole operator: rtol follows the tunnel diagonal where it contributes
+    np.testing.assert_allclose(v["dinv"], T.dinv[r0:r0 + nr], rtol=1e-10)
+    plain = np.ones(nr, bool)
+    own = T.sub_rows[(T.sub_rows >= r0) & (T.sub_rows < r0 + nr)] - r0
+    plain[own] = False
+    np.testing.assert_allclose(v["dinv"][plain], T.dinv[r0:r0 + nr][plain], rtol=1e-13)
+    return tn
+
+
+def test_small_device_single_rank(km, oracle, torch):
+    S = km.solvers
+    d = small_device(seed=7)
+    a = 2.5
+    x_lo, x_hi = (d["layers"] - 1) * a - 0.1, (d["layers"] + 7) * a + 0.1
+    metals = np.array([TI, N_EL], np.int32)
+    T = oracle.TSystem(d["xyz"], d["element"], d["charge"], d["cb"], metals, PAR["nn_dist"], d["n1"], d["n1"], d["layers"],
+                       PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], PAR["tol"], PAR["m_e"], PAR["V0"], x_lo, x_hi)
+    comm = S.KMC_comm(T.Nsub, T.Nsub, len(d["element"]), len(d["element"]))
+    comm.connect()
+    buf = _make(km, torch, d["xyz"], d["element"], d["charge"], d["cb"], metals, d["n1"], d["layers"], comm)
+    assert buf.N_atom_ == T.N_atom
+    np.testing.assert_array_equal(S.t_atom_sites(buf), T.atom_site)
+    prm = S.current_params(PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], G0, PAR["tol"], PAR["m_e"], PAR["V0"],
+                           contact_x_lo=x_lo, contact_x_hi=x_hi)
+    S.t_assemble(buf, prm)
+    _compare_assembly(S, buf, T)
+    # the split operator through the generic SpMV entry
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
+    x = np.cos(np.arange(T.Nsub) * 0.7) + 1.5
+    p = torch.as_tensor(x, device="cuda")
+    Ap = torch.empty_like(p)
+    mat.spmv(p, Ap)
+    M = T.merged_csr()
+    assert np.all(np.abs(Ap.cpu().numpy() - T.spmv(x)) <= 1e-12 * (abs(M) @ np.abs(x)))
+    # current and power kernels on prescribed potentials (0 CG iterations leave the start vector untouched):
+    # I_macro is a sum of differences of nearly equal potentials, so it is compared on identical inputs
+    rng = np.random.default_rng(1)
+    x0 = PAR["Vd"] * (0.5 + 0.5 * np.cos(np.arange(T.Nsub) * 0.05)) + 1e-3 * rng.standard_normal(T.Nsub)
+    kw = dict(contact_x_lo=x_lo, contact_x_hi=x_hi)
+    args = (d["n1"], d["n1"], d["layers"], PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], G0, PAR["tol"], PAR["nn_dist"],
+            PAR["m_e"], PAR["V0"], 2)
+    for heating in (False, True):
+        buf.atom_virtual_potentials.zero_()
+        buf.atom_virtual_potentials[:T.Nsub] = torch.as_tensor(x0, device="cuda")
+        buf.site_power.fill_(-7.0)
+        im, st = S.update_power_gpu_sparse_dist(buf, *args, heating, False, 1.0, cg_tolerance=1e-30, cg_max_iterations=0, **kw)
+        assert st["iterations"] == 0
+        m = np.zeros(T.N_atom + 2)
+        m[:T.Nsub] = x0 * G0
+        imo = T.imacro(m)
+        assert abs(im - imo) <= 1e-11 * np.abs(T.val[T.row_ptr[1]:T.row_ptr[2]] * m[1]).sum(), (im, imo)
+        got = buf.atom_virtual_potentials.cpu().numpy()
+        if not heating:
+            np.testing.assert_array_equal(got, m)
+            assert np.all(buf.site_power.cpu().numpy() == -7.0)
+        else:
+            pw = np.full(len(d["element"]), -7.0)
+            T.power(m, 1.0, pw)                          # shifts m in place
+            np.testing.assert_allclose(got, m, rtol=1e-15, atol=0)
+            gp = buf.site_power.cpu().numpy()
+            np.testing.assert_array_equal(gp == -7.0, pw == -7.0)
+            assert np.abs(gp - pw).max() <= 1e-11 * np.abs(pw[pw != -7.0]).max()
+    # the CG's wiring (split SpMV, preconditioner, dots): iterates after 5 iterations from zero
+    buf.atom_virtual_potentials.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, *args, False, False, 1.0, cg_tolerance=1e-30, cg_max_iterations=5, **kw)
+    xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-30, 5)
+    assert st["iterations"] == ito == 5
+    got = buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub] / G0
+    assert np.abs(got - xo).max() <= 1e-10 * np.abs(xo).max()
+    # converged solve: stopping rule, iteration count, warm restart
+    buf.atom_virtual_potentials.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, d["n1"], d["n1"], d["layers"], PAR["Vd"], PAR["high_G"], PAR["low_G"],
+                                            PAR["loop_G"], G0, PAR["tol"], PAR["nn_dist"], PAR["m_e"], PAR["V0"], 2, False, False,
+                                            1.0, cg_tolerance=1e-13, cg_max_iterations=20000, contact_x_lo=x_lo, contact_x_hi=x_hi)
+    xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-13, 20000)
+    assert st["converged"] == 1 and st["relres"] <= 1e-13
+    assert abs(st["iterations"] - ito) <= max(3, 0.05 * ito), (st["iterations"], ito)
+    v = buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub] / G0
+    res = T.rhs - T.spmv(v)
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(T.rhs)
+    tight = np.r_[0, 1, 2 + np.nonzero(np.isin(T.atom_element[:-1], [TI, N_EL]))[0]]
+    assert np.abs(v[tight] - xo[tight]).max() <= 2e-6 * np.abs(xo).max()
+    assert im > 0
+    buf.freeGPUmemory()
+    comm.close()
+
+
+def test_5nm_device(km, oracle, dev5, ref5, torch):
+    """The reference's 5 nm device with solve_current on (BASELINE config 3's path at config 1's size):
+    25 682-row neighbour matrix (two 578-entry virtual-node rows), 1913 tunnel points, 36 % dense block."""
+    S = km.solvers
+    d = dev5
+    NL = d["N_contact"]
+    comm = S.KMC_comm(d["N"] - 2 * NL, 25682, d["N"], d["N"])
+    comm.connect()
+    buf = S.GPUBuffers(d["N"], d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"], d["k"],
+                       d["lattice"], d["metals"])
+    S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
+    S.initialize_sparsity_K(buf, d["pbc"], d["nn_dist"], NL, comm)
+    buf.site_charge.copy_(torch.as_tensor(ref5["charge"]))
+    # conduction-band edge on the GPU (update_CB_edge_gpu_sparse); the oracle gets the same array so that the
+    # |dE| > tol decisions of the tunnel pattern are taken on identical numbers
+    S.update_CB_edge_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
+    cb = buf.site_CB_edge.cpu().numpy()
+    high_G, low_G, loop_G = 1e5 * d["high_G"], d["low_G"], 1e7 * d["high_G"]      # src/kmc_main.cpp:294-296
+    tol, m_e, V0 = Q * 0.01, 0.85 * 9.11e-31, 1.6
+    T = oracle.TSystem(d["xyz"], d["element"], ref5["charge"], cb, d["metals"], d["nn_dist"], NL, NL, 10, d["Vd"], high_G, low_G,
+                       loop_G, tol, m_e, V0)
+    S.initialize_sparsity_T(buf, d["pbc"], d["nn_dist"], NL, NL, 10, comm)
+    assert buf.N_atom_ == T.N_atom == 25681
+    prm = S.current_params(d["Vd"], high_G, low_G, loop_G, G0, tol, m_e, V0)
+    S.t_assemble(buf, prm)
+    tn = _compare_assembly(S, buf, T)
+    info = S.t_info(buf)
+    assert info["tunnel_points"] == 1913 and info["nnz_tunnel"] == len(T.sub_col)
+    minfo = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed)).info()
+    assert minfo["spmv_kind"] == 2          # the virtual-node rows did not push the matrix off the window kernel
+    # current and power on prescribed potentials (see test_small_device_single_rank)
+    rng = np.random.default_rng(2)
+    ax = d["xyz"][T.atom_site, 0]
+    x0 = np.zeros(T.Nsub)
+    x0[0], x0[1] = 0.0, d["Vd"]
+    x0[2:] = d["Vd"] * np.clip(1 - ax[:-1] / 52.0, 0, 1) + 1e-3 * rng.standard_normal(T.N_atom - 1)
+    args = (NL, NL, 10, d["Vd"], high_G, low_G, loop_G, G0, tol, d["nn_dist"], m_e, V0, len(d["metals"]))
+    buf.atom_virtual_potentials.zero_()
+    buf.atom_virtual_potentials[:T.Nsub] = torch.as_tensor(x0, device="cuda")
+    im, st = S.update_power_gpu_sparse_dist(buf, *args, True, False, 1.0, cg_tolerance=1e-30, cg_max_iterations=0)
+    m = np.zeros(T.N_atom + 2)
+    m[:T.Nsub] = x0 * G0
+    imo = T.imacro(m)
+    assert abs(im - imo) <= 1e-11 * np.abs(T.val[T.row_ptr[1]:T.row_ptr[2]] * m[1]).sum(), (im, imo)
+    pw = np.zeros(d["N"])
+    T.power(m, 1.0, pw)
+    np.testing.assert_allclose(buf.atom_virtual_potentials.cpu().numpy(), m, rtol=1e-15, atol=0)
+    gp = buf.site_power.cpu().numpy()
+    assert np.abs(gp - pw).max() <= 1e-10 * np.abs(pw).max() and pw.max() > 0
+    # the reference's benchmark setting: 100 iterations whatever the residual (current_solver_gpu.cu:1455-1456);
+    # iterates of the two implementations agree while rounding has not yet been amplified (5 iterations checked)
+    buf.atom_virtual_potentials.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, *args, False, False, 1.0)
+    assert st["iterations"] == 100 and st["converged"] == 0
+    buf.atom_virtual_potentials.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, *args, False, False, 1.0, cg_tolerance=1e-30, cg_max_iterations=5)
+    xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-30, 5)
+    got = buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub] / G0
+    assert st["iterations"] == ito == 5 and np.abs(got - xo).max() <= 1e-10 * np.abs(xo).max()
+    # converged (the reference's commented-out tolerance 1e-15 * N_atom), cold then warm
+    buf.atom_virtual_potentials.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, *args, False, False, 1.0, cg_tolerance=1e-15 * T.N_atom, cg_max_iterations=2000)
+    xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-15 * T.N_atom, 2000)
+    # conductances from 1e7 (loop) to 1e-17 (far tunnel pairs): the Jacobi-PCG count moves with the summation
+    # order of the dots by ~10 % here (measured 349 in brick order on the GPU against 316 in natural order in the
+    # oracle; 2 % on the K system, whose span is 1e8) -- held to 15 %, the solution to the bars below
+    assert st["converged"] == 1 and abs(st["iterations"] - ito) <= 0.15 * ito, (st, ito)
+    print("T 5 nm: %d iterations (oracle %d), assembly %.3f ms, solve %.3f ms" % (st["iterations"], ito, st["ms_assembly"], st["ms_solve"]))
+    v = buf.atom_virtual_potentials.cpu().numpy() / G0
+    assert abs(v[1] - d["Vd"]) < 1e-3 and abs(v[NL] - d["Vd"]) < 0.1          # the reference's sanity check (:2014-2020)
+    res = T.rhs - T.spmv(v[:T.Nsub])
+    assert np.linalg.norm(res) / np.linalg.norm(T.rhs) <= 1e-6
+    assert im > 0
+    buf.freeGPUmemory()
+    comm.close()
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_small_device_multirank(km, oracle, torch, P):
+    """Row-partitioned T over a loopback group: halo exchange of the neighbour part, all-gather of the tunnel
+    sub-vector, replicated current and power."""
+    S = km.solvers
+    d = small_device(seed=11)
+    a = 2.5
+    x_lo, x_hi = (d["layers"] - 1) * a - 0.1, (d["layers"] + 7) * a + 0.1
+    metals = np.array([TI, N_EL], np.int32)
+    T = oracle.TSystem(d["xyz"], d["element"], d["charge"], d["cb"], metals, PAR["nn_dist"], d["n1"], d["n1"], d["layers"],
+                       PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], PAR["tol"], PAR["m_e"], PAR["V0"], x_lo, x_hi)
+    N = len(d["element"])
+    comms = S.KMC_comm.loopback_group(T.Nsub, T.Nsub, N, N, P)
+    out, errs = [None] * P, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = comms[r]
+            buf = _make(km, torch, d["xyz"], d["element"], d["charge"], d["cb"], metals, d["n1"], d["layers"], comm)
+            prm = S.current_params(PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], G0, PAR["tol"], PAR["m_e"], PAR["V0"],
+                                   contact_x_lo=x_lo, contact_x_hi=x_hi)
+            S.t_assemble(buf, prm)
+            r0, nr = int(comm.displs_T[r]), int(comm.counts_T[r])
+            _compare_assembly(S, buf, T, r0, nr)
+            buf.site_power.fill_(-7.0)
+            im, st = S.update_power_gpu_sparse_dist(buf, d["n1"], d["n1"], d["layers"], PAR["Vd"], PAR["high_G"], PAR["low_G"],
+                                                    PAR["loop_G"], G0, PAR["tol"], PAR["nn_dist"], PAR["m_e"], PAR["V0"], 2, True,
+                                                    False, 1.0, cg_tolerance=1e-13, cg_max_iterations=20000, contact_x_lo=x_lo,
+                                                    contact_x_hi=x_hi)
+            out[r] = dict(im=im, st=st, v=buf.atom_virtual_potentials.cpu().numpy().copy(),
+                          pw=buf.site_power.cpu().numpy().copy())
+            buf.freeGPUmemory()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(180)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out), "a rank did not finish"
+    for c in comms:
+        c.close()
+    xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-13, 20000)
+    m = np.zeros(T.N_atom + 2)
+    m[:T.Nsub] = xo * G0
+    imo = T.imacro(m)
+    pw = np.full(N, -7.0)
+    T.power(m, 1.0, pw)
+    for o in out:
+        assert o["st"]["converged"] == 1 and abs(o["st"]["iterations"] - ito) <= max(3, 0.05 * ito)
+        assert o["im"] > 0 and abs(o["im"] - out[0]["im"]) == 0
+        np.testing.assert_array_equal(o["v"], out[0]["v"])             # replicated bit for bit
+        np.testing.assert_array_equal(o["pw"], out[0]["pw"])
+        np.testing.assert_array_equal(o["pw"] == -7.0, pw == -7.0)
+        tight = np.r_[0, 1, 2 + np.nonzero(np.isin(T.atom_element[:-1], [TI, N_EL]))[0]]
+        assert np.abs(o["v"][tight] - m[tight]).max() <= 2e-6 * np.abs(m).max()

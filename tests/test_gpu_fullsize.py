@@ -146,3 +146,92 @@ def test_full_size_event_step_bookkeeping(full, km):
     for _ in range(2 * nev):
         probe.getRandomNumber()
     assert rng.getRandomNumber() == probe.getRandomNumber()                          # two draws per event
+
+
+def test_full_size_current_and_heat(full, km):
+    """BASELINE config 3 at full size: conduction-band edge, T assembly (1 046 913-row neighbour matrix whose two
+    virtual-node rows hold 19 200 entries each: the long-row kernel; tunnel sub-block over the 19 697 vacancies:
+    the authors' shape class, >= 10 k rows and >= 40 % dense, main_test_cg_split.cpp:1030-1035), split-operator PCG,
+    current, dissipated power and the global temperature update -- checked through properties (no reference result
+    of this size exists; parity unpinned): rows of the Kirchhoff operator sum to their ground conductance, the
+    operator is symmetric, the solution obeys its stopping rule on the true residual and the maximum principle,
+    current flows in, power is non-negative and lands on non-metal atoms only, the heat update equals its closed
+    form on the power the GPU produced."""
+    S, d, buf, comm, t = full["S"], full["d"], full["buf"], full["comm"], full["torch"]
+    NL = d["N_contact"]
+    Q = 1.60217663e-19
+    S.update_CB_edge_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
+    el = buf.site_element.cpu().numpy()
+    atom = (el != 0) & (el != 1)
+    N_atom = int(atom.sum())
+    comm.counts_T, comm.displs_T = comm.partition(N_atom + 1, 1)       # kmc_comm.counts_T: N_atom + 1 rows (kmc_main.cpp:165-171)
+    S.initialize_sparsity_T(buf, d["pbc"], d["nn_dist"], NL, NL, 10, comm)
+    assert buf.N_atom_ == N_atom
+    high_G, low_G, loop_G = 1e5 * d["high_G"], d["low_G"], 1e7 * d["high_G"]
+    G0 = 2 * 3.8612e-5 * 1e-5
+    # vacancies only as tunnel points (an empty contact window): with the reference's hard-coded window the block
+    # would have 70 k rows and ~1.7e9 entries
+    kw = dict(contact_x_lo=1.0, contact_x_hi=0.0)
+    prm = S.current_params(d["Vd"], high_G, low_G, loop_G, G0, Q * 0.01, 0.85 * 9.11e-31, 1.6, **kw)
+    S.t_assemble(buf, prm)
+    info = S.t_info(buf)
+    n = info["Nsub"]
+    assert info["tunnel_points"] == int((el == 2).sum()) >= 10000
+    dens = info["nnz_tunnel"] / info["tunnel_points"] ** 2
+    assert dens >= 0.4, dens
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
+    minfo = mat.info()
+    assert minfo["spmv_kind"] == 2 and minfo["spmv_coded"] == CODED_ON     # long rows did not displace the window kernel
+
+    def tspmv(x):
+        p = t.as_tensor(np.ascontiguousarray(x), device="cuda")
+        Ap = t.empty_like(p)
+        mat.spmv(p, Ap)
+        return Ap.cpu().numpy()
+
+    v = S.t_vectors(buf)
+    # T 1 = ground conductances: high_G for the extraction node and for the atoms next to the cut ground atom
+    y = tspmv(np.ones(n))
+    scale = 1.0 / v["dinv"]
+    assert np.all(np.abs(y - np.round(y / high_G) * high_G) <= 1e-11 * scale)
+    gnd = np.round(y / high_G).astype(int)
+    assert set(np.unique(gnd)) <= {0, 1} and gnd[0] == 1 and gnd[1] == 0 and 2 <= gnd.sum() <= 60
+    rng = np.random.default_rng(4)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    Ta, Tb = tspmv(a), tspmv(b)
+    assert abs(np.dot(b, Ta) - np.dot(a, Tb)) <= 1e-11 * (np.linalg.norm(a) * np.linalg.norm(Tb))
+    # solve (the reference's commented-out tolerance), current, power
+    buf.atom_virtual_potentials.zero_()
+    buf.site_power.zero_()
+    im, st = S.update_power_gpu_sparse_dist(buf, NL, NL, 10, d["Vd"], high_G, low_G, loop_G, G0, Q * 0.01, d["nn_dist"],
+                                            0.85 * 9.11e-31, 1.6, len(d["metals"]), True, True, 1.0,
+                                            cg_tolerance=1e-15 * N_atom, cg_max_iterations=20000, **kw)
+    print("T 40 nm: %d rows, %d tunnel points (%.0f %% dense, %.2f GB), %d iterations, assembly %.2f ms, solve %.1f ms"
+          % (n, info["tunnel_points"], 100 * dens, info["nnz_tunnel"] * 8e-9, st["iterations"], st["ms_assembly"], st["ms_solve"]))
+    assert st["converged"] == 1 and st["relres"] <= 1e-15 * N_atom
+    m = buf.atom_virtual_potentials.cpu().numpy()
+    pw = buf.site_power.cpu().numpy()
+    metal = np.isin(el, d["metals"])
+    assert np.all(pw[metal | ~atom] == 0) and np.all(pw >= 0) and pw.max() > 0
+    # I_macro = high_G * sum over the 19 200 injection atoms of (m[1] - m[atom]): differences of potentials that
+    # agree to ~1e-9 relative at this stopping tolerance, i.e. rounding-level at full size (the sign is checked
+    # where the solve is tighter: tests/test_gpu_tpath.py); here: finite and bounded by the solution's accuracy
+    assert np.isfinite(im) and abs(im) <= high_G * NL * np.abs(m).max() * 1e-6
+    # maximum principle: the only sources are the two driver nodes (sink at 0, source at 1) and the ground (the cut
+    # atom, potential 0), so every atom lies between them.  m is scaled by G0 and was shifted by |min over atoms and
+    # the ground entry| for the power step: the ground entry m[N_atom + 1] carries that shift.
+    pot = (m[:n] - m[n]) / G0
+    lo, hi = min(pot[0], 0.0), max(pot[1], 0.0)
+    # ... checked on the metallic network: an atom coupled only through low_G (diagonal ~1e-8) may be off by volts
+    # under the stopping rule r.z / b.b <= tol^2 with b.b = 2 (loop_G Vd)^2 -- the conditioning, not a kernel property
+    mpot = pot[2:][metal[atom][:-1]]
+    assert mpot.min() >= lo - 1e-3 * d["Vd"] and mpot.max() <= hi + 1e-3 * d["Vd"]
+    assert abs(pot[1] - pot[0] - d["Vd"]) < 1e-2 * d["Vd"]
+    # heat: Sum site_power -> T_bg (update_temperatureglobal_gpu) against the closed form on the same power
+    a_c, b_c, nsteps, C_th, small = 0.9, 30.0, 25.0, 1e-12, 1e-9
+    buf.T_bg.fill_(300.0)
+    S.update_temperatureglobal_gpu(buf.site_power, buf.T_bg, d["N"], a_c, b_c, nsteps, C_th, small, comm)
+    c_c = b_c + pw.sum() / C_th * small
+    want = c_c * (1 - a_c ** 25) / (1 - a_c) + a_c ** 25 * 300.0
+    assert abs(float(buf.T_bg.cpu()[0]) - want) <= 1e-12 * abs(want)
+    S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])          # the CB-edge solve left its own system in K

@@ -6,10 +6,13 @@
 //     // src/kmcfield_backend.cpp
 //     #include "kmcfield_compat.hpp"
 //
-// in place of the bodies of initialize_sparsity_K (src/iterative_solvers_gpu.cu:262-488),
-// compute_neighbor_list (src/neighbor_lists_gpu.cu:252-292), update_charge_gpu,
-// background_potential_gpu_sparse, sum_and_gather_potential (src/potential_solver_gpu.cu:66-85,
-// 846-1151) and update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70), and link
+// in place of the bodies of initialize_sparsity_K / initialize_sparsity_CB (src/iterative_solvers_gpu.cu:262-488,
+// 199-260), compute_neighbor_list / compute_cutoff_list (src/neighbor_lists_gpu.cu:252-372), update_charge_gpu,
+// background_potential_gpu_sparse, update_CB_edge_gpu_sparse, poisson_gridless_gpu, sum_and_gather_potential
+// (src/potential_solver_gpu.cu), initialize_sparsity_T (src/initialize_sparsity_T.cu:948-1154),
+// update_power_gpu_sparse_dist (src/current_solver_gpu.cu:1430-1855), execute_kmc_step_mpi / copytoConstMemory
+// (src/kmc_events.cu) and update_temperatureglobal_gpu (src/heat_solver_gpu.cu:53-70) -- every gpu_solvers.h
+// entry point src/kmc_main.cpp calls -- and link
 // -lkmcfield.  src/kmc_main.cpp, Device, KMCProcess, GPUBuffers and KMC_comm stay unchanged:
 // the signatures below are the reference's own.
 //
@@ -35,13 +38,20 @@ inline void check(int rc, const char *what)
     }
 }
 
-// One libkmcfield communicator per MPI communicator (comm_K, comm_events ...).  The RCCL unique
-// ids are created on rank 0 and broadcast with the MPI the reference already has.
+// One libkmcfield communicator per GROUP of ranks: comm_K, comm_T, comm_events, comm_pairwise and
+// MPI_COMM_WORLD have the same members in the same order when split = false (src/KMC_comm.h:225-243), and
+// share one kmcf_comm (two RCCL communicators) instead of one each.  The RCCL unique ids are created on rank
+// 0 and broadcast with the MPI the reference already has.
 inline kmcf_comm *comm_of(MPI_Comm mpi)
 {
     static std::map<MPI_Comm, kmcf_comm *> table;
     auto it = table.find(mpi);
     if (it != table.end()) return it->second;
+    for (auto &kv : table) {
+        int cmp = MPI_UNEQUAL;
+        MPI_Comm_compare(mpi, kv.first, &cmp);
+        if (cmp == MPI_IDENT || cmp == MPI_CONGRUENT) { table[mpi] = kv.second; return kv.second; }
+    }
     int rank = 0, size = 1, device = 0;
     MPI_Comm_rank(mpi, &rank);
     MPI_Comm_size(mpi, &size);
@@ -63,6 +73,8 @@ inline kmcf_comm *comm_of(MPI_Comm mpi)
 // gpubuf.K_distributed is a Distributed_matrix* in the reference; main never dereferences it
 // (it only passes gpubuf around), so the slot carries the opaque libkmcfield K state.
 inline kmcf_kstate *kstate_of(GPUBuffers &gpubuf) { return reinterpret_cast<kmcf_kstate *>(gpubuf.K_distributed); }
+// likewise gpubuf.T_distributed (+ T_p_distributed and the atom_* arrays, which only the T functions touch)
+inline kmcf_tstate *tstate_of(GPUBuffers &gpubuf) { return reinterpret_cast<kmcf_tstate *>(gpubuf.T_distributed); }
 
 static_assert(sizeof(ELEMENT) == sizeof(int), "ELEMENT must be a 4-byte enum (src/utils.h:37-44)");
 
@@ -98,6 +110,67 @@ void initialize_sparsity_K(GPUBuffers &gpubuf, int pbc, const double nn_dist, in
                                                   nn_dist, num_atoms_contact, kmc_comm.counts_K, kmc_comm.displs_K, &k),
                        "kmcf_initialize_sparsity_K");
     gpubuf.K_distributed = reinterpret_cast<Distributed_matrix *>(k);
+}
+
+// src/iterative_solvers_gpu.cu:199-260: the reference builds a second, single-GPU copy of the K pattern for the
+// conduction-band-edge solve; update_CB_edge_gpu_sparse below works on the K state's own pattern instead.
+void initialize_sparsity_CB(GPUBuffers &gpubuf, int pbc, const double nn_dist, int num_atoms_contact)
+{
+    (void)pbc; (void)nn_dist; (void)num_atoms_contact;
+    if (!kmcf_compat::kstate_of(gpubuf)) {
+        std::fprintf(stderr, "kmcfield: initialize_sparsity_CB needs initialize_sparsity_K first\n");
+        std::exit(1);
+    }
+}
+
+// src/initialize_sparsity_T.cu:948-1154, once per bias point (src/kmc_main.cpp:273)
+void initialize_sparsity_T(GPUBuffers &gpubuf, int pbc, const double nn_dist, int num_source_inj, int num_ground_ext,
+                           int num_layers_contact, KMC_comm &kmc_comm)
+{
+    (void)pbc;     // the reference's T kernels use the non-periodic distance whatever pbc says (gpu_solvers.h:280-285)
+    if (kmcf_compat::tstate_of(gpubuf)) kmcf_compat::check(kmcf_tstate_destroy(kmcf_compat::tstate_of(gpubuf)), "kmcf_tstate_destroy");
+    kmcf_tstate *t = nullptr;
+    kmcf_compat::check(kmcf_initialize_sparsity_T(kmcf_compat::comm_of(kmc_comm.comm_T), gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
+                                                  reinterpret_cast<const int *>(gpubuf.site_element), gpubuf.N_, nn_dist,
+                                                  num_source_inj, num_ground_ext, num_layers_contact, kmc_comm.counts_T,
+                                                  kmc_comm.displs_T, &t), "kmcf_initialize_sparsity_T");
+    gpubuf.T_distributed = reinterpret_cast<Distributed_matrix *>(t);
+    kmcf_tstate_info_t info;
+    kmcf_compat::check(kmcf_tstate_info(t, &info), "kmcf_tstate_info");
+    gpubuf.N_atom_ = info.N_atom;                                          // update_atom_arrays, current_solver_gpu.cu:1355
+}
+
+// src/current_solver_gpu.cu:1430-1855 (gpu_solvers.h:212).  CG settings are the reference's
+// (relative_tolerance = 1e-30 * N_atom, max_iterations = 100, :1455-1456); the contact window of the tunnel
+// points its hard-coded -4.2 .. 52.65 A (src/initialize_sparsity_T.cu:645).  What the reference has behind its
+// benchmark exit(1) -- I_macro and the dissipated power -- is computed (kmcfield.h).
+void update_power_gpu_sparse_dist(hipblasHandle_t, hipsolverDnHandle_t, GPUBuffers &gpubuf, const int num_source_inj,
+                                  const int num_ground_ext, const int num_layers_contact, const double Vd,
+                                  const double high_G, const double low_G, const double loop_G, const double G0,
+                                  const double tol, const double nn_dist, const double m_e, const double V0, int num_metals,
+                                  double *imacro, const bool solve_heating_local, const bool solve_heating_global,
+                                  const double alpha_disp)
+{
+    (void)num_source_inj; (void)num_ground_ext; (void)num_layers_contact; (void)nn_dist;   // fixed at initialize_sparsity_T
+    kmcf_current_params_t p;
+    p.Vd = Vd; p.high_G = high_G; p.low_G = low_G; p.loop_G = loop_G; p.G0 = G0; p.tol = tol; p.m_e = m_e; p.V0 = V0;
+    p.alpha_disp = alpha_disp;
+    p.contact_x_lo = -4.2; p.contact_x_hi = 52.65;
+    p.cg_tolerance = 1e-30 * gpubuf.N_atom_;
+    p.cg_max_iterations = 100;
+    p.solve_heating = (solve_heating_local || solve_heating_global) ? 1 : 0;
+    kmcf_solve_stats_t st;
+    kmcf_compat::check(kmcf_update_power_sparse(kmcf_compat::tstate_of(gpubuf), reinterpret_cast<const int *>(gpubuf.site_element),
+                                                gpubuf.site_charge, gpubuf.site_CB_edge,
+                                                reinterpret_cast<const int *>(gpubuf.metal_types), num_metals,
+                                                gpubuf.atom_virtual_potentials, gpubuf.site_power, &p, imacro, &st),
+                       "kmcf_update_power_sparse");
+    int rank = 0;
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    if (rank == 0) {   // dist_conjugate_gradient_split_sparse.cpp:170-172, current_solver_gpu.cu:1823
+        std::printf("iteration (T) = %d, relative residual = %g\n", st.iterations + 1, st.relres);
+        std::printf("I_macro: %g\n", *imacro * (1e6));
+    }
 }
 
 // src/potential_solver_gpu.cu:66-85

@@ -16,6 +16,7 @@
 //
 // HBM traffic per iteration besides the SpMV: p update 3R+1W, x/r update 5R+2W
 // vector passes = 88 B/row (the reference's op sequence: 144 B/row).
+#include <chrono>
 #include <cmath>
 
 #include "kmcf_internal.hpp"
@@ -219,8 +220,30 @@ int vec_grid(int n)
     return (int)g;
 }
 
+// Reads back the scalars of the solve enqueued last (after ONE stream synchronisation) and fills `stats`.
+int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *stats)
+{
+    kmcf_comm *c = m->comm;
+    KMCF_HIP(hipStreamSynchronize(c->stream));
+    if (c->nranks > 1 || c->force_collectives) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    const kmcf_scalars &hS = *c->h_scal;
+    if (stats) {
+        stats->iterations = hS.iters;
+        stats->bb = hS.bb;
+        stats->rz = hS.rz_last;
+        stats->relres = std::sqrt(hS.rz_last / hS.bb);
+        stats->converged = (hS.done != 0) || !((absolute ? hS.rz_last : hS.rz_last / hS.bb) > tol2);
+        float ms = 0.f;
+        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        stats->ms_solve = ms;
+    }
+    return KMCF_OK;
+}
+
+// flags: bit 0 = d_p already holds x0 (the fused input kernel wrote it), bit 1 = leave the final synchronisation and
+// the statistics to the caller (pcg_collect), who has more work to enqueue first
 template <bool PRECOND>
-int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolute, kmcf_solve_stats_t *stats)
+int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolute, kmcf_solve_stats_t *stats, int flags = 0)
 {
     kmcf_comm *c = m->comm;
     hipStream_t st = c->stream;
@@ -243,7 +266,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
     // p <- x0 ; Ap = A x0 ; r = b - Ap ; z ; r.z ; b.b    (:178-213)
-    KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (!(flags & 1)) KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     KMCF_TRY(kmcf_spmv_device(m, false, false));
     cg_init_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, m->d_part_b, m->d_part_c);
     KMCF_HIP(hipGetLastError());
@@ -297,21 +320,9 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
         KMCF_HIP(hipGetLastError());
     }
     KMCF_HIP(hipEventRecord(c->ev_t1, st));
-    kmcf_scalars hS;
-    KMCF_HIP(hipMemcpyAsync(&hS, S, sizeof(hS), hipMemcpyDeviceToHost, st));
-    KMCF_HIP(hipStreamSynchronize(st));
-    if (multi) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
-    if (stats) {
-        stats->iterations = hS.iters;
-        stats->bb = hS.bb;
-        stats->rz = hS.rz_last;
-        stats->relres = std::sqrt(hS.rz_last / hS.bb);
-        stats->converged = (hS.done != 0) || !((absolute ? hS.rz_last : hS.rz_last / hS.bb) > tol2);
-        float ms = 0.f;
-        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-        stats->ms_solve = ms;
-    }
-    return KMCF_OK;
+    if (flags & 2) return KMCF_OK;                 // the caller's output kernel writes the scalars to the host
+    KMCF_HIP(hipMemcpyAsync(c->h_scal, S, sizeof(kmcf_scalars), hipMemcpyDeviceToHost, st));
+    return pcg_collect(m, tol2, absolute, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_finalize_kernel(part_ref pg, p
 }
 
 template <bool PRECOND>
-int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
+int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags = 0)
 {
     kmcf_comm *c = m->comm;
     hipStream_t st = c->stream;
@@ -433,7 +444,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
 
     KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
-    KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (!(flags & 1)) KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     KMCF_TRY(kmcf_spmv_device(m, false, false));                       // A x0
     cg1_init_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, m->d_p, m->d_part_b, m->d_part_c);
     KMCF_HIP(hipGetLastError());
@@ -476,38 +487,31 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
         KMCF_HIP(hipGetLastError());
     }
     KMCF_HIP(hipEventRecord(c->ev_t1, st));
-    kmcf_scalars hS;
-    KMCF_HIP(hipMemcpyAsync(&hS, S, sizeof(hS), hipMemcpyDeviceToHost, st));
-    KMCF_HIP(hipStreamSynchronize(st));
-    if (multi) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
-    if (stats) {
-        stats->iterations = hS.iters;
-        stats->bb = hS.bb;
-        stats->rz = hS.rz_last;
-        stats->relres = std::sqrt(hS.rz_last / hS.bb);
-        stats->converged = (hS.done != 0) || !(hS.rz_last / hS.bb > tol2);
-        float ms = 0.f;
-        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-        stats->ms_solve = ms;
-    }
-    return KMCF_OK;
+    if (flags & 2) return KMCF_OK;
+    KMCF_HIP(hipMemcpyAsync(c->h_scal, S, sizeof(kmcf_scalars), hipMemcpyDeviceToHost, st));
+    return pcg_collect(m, tol2, 0, stats);
 }
 
 }  // namespace
 
 // Solve on the matrix workspace: m->d_r holds b, m->d_x the start guess, m->d_dinv 1/diag.
-int kmcf_pcg_workspace(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
+static int pcg_workspace_flags(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
 {
     // classic = the reference's recurrence and operation order (default for one rank);
     // cg1r = single-reduction variant (default for multi-rank groups)
     bool cg1r = m->comm->nranks > 1;
     if (const char *e = getenv("KMCF_CG_VARIANT")) cg1r = (e[0] == 'c' && e[1] == 'g');
     if (cg1r) {
-        if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats);
-        return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats);
+        if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
+        return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }
-    if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats);
-    return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats);
+    if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats, flags);
+    return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats, flags);
+}
+
+int kmcf_pcg_workspace(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats)
+{
+    return pcg_workspace_flags(m, precond, tol, max_it, fixed_iters, stats, 0);
 }
 
 namespace {
@@ -586,6 +590,36 @@ extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double
     return KMCF_OK;
 }
 
+namespace {
+// The caller's r, x and 1/diag into the (internally ordered, aligned) workspace in ONE pass; p <- x0 on the way.
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_in_kernel(int n, const int *__restrict__ perm, const double *__restrict__ r_u,
+                                                           const double *__restrict__ x_u, const double *__restrict__ dinv_u,
+                                                           double *__restrict__ r, double *__restrict__ x, double *__restrict__ p,
+                                                           double *__restrict__ dinv)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int s = perm ? perm[i] : i;
+        const double xv = x_u[s];
+        r[i] = r_u[s];
+        x[i] = xv;
+        p[i] = xv;
+        if (dinv_u) dinv[i] = dinv_u[s];
+    }
+}
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_out_kernel(int n, const int *__restrict__ perm, const double *__restrict__ r,
+                                                            const double *__restrict__ x, double *__restrict__ r_u, double *__restrict__ x_u,
+                                                            const kmcf_scalars *__restrict__ S, kmcf_scalars *__restrict__ host_S)
+{
+    // the solve's scalars straight into pinned host memory: a 120-byte hipMemcpyAsync costs tens of microseconds
+    if (host_S && blockIdx.x == 0 && threadIdx.x == 0) *host_S = *S;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int s = perm ? perm[i] : i;
+        r_u[s] = r[i];
+        x_u[s] = x[i];
+    }
+}
+}  // namespace
+
 extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const double *d_diag_inv,
                                double relative_tolerance, int max_iterations, int fixed_iters,
                                kmcf_solve_stats_t *stats)
@@ -599,14 +633,28 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     // the caller's vectors may be unaligned slices (x is gpubuf.site_potential_boundary +
     // N_left + disp, src/potential_solver_gpu.cu:861) and are in the caller's row order: work on
     // the aligned, internally ordered workspace
-    KMCF_TRY(kmcf_vec_in(m, m->d_r, d_r));
-    KMCF_TRY(kmcf_vec_in(m, m->d_x, d_x));
-    if (d_diag_inv) KMCF_TRY(kmcf_vec_in(m, m->d_dinv, d_diag_inv));
-    KMCF_TRY(kmcf_pcg_workspace(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats));
-    KMCF_TRY(kmcf_vec_out(m, d_r, m->d_r));
-    KMCF_TRY(kmcf_vec_out(m, d_x, m->d_x));
-    KMCF_HIP(hipStreamSynchronize(c->stream));   // results visible on return (:271 hipDeviceSynchronize)
-    return KMCF_OK;
+    // one pass in, one pass out, ONE host synchronisation at the end of the whole call (a fixed-iteration solve
+    // -- the benchmark's step -- otherwise pays three input kernels, a copy, two output kernels and two syncs)
+    const int n = m->n_loc;
+    const bool trace = getenv("KMCF_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = trace ? now() : 0.0;
+    if (n > 0) {
+        cg_in_kernel<<<vec_grid(n), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, d_r, d_x, d_diag_inv, m->d_r, m->d_x, m->d_p, m->d_dinv);
+        KMCF_HIP(hipGetLastError());
+    }
+    KMCF_TRY(pcg_workspace_flags(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats, 1 | 2));
+    const double t_b = trace ? now() : 0.0;
+    cg_out_kernel<<<vec_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, d_r, d_x, m->d_S, c->h_scal);
+    KMCF_HIP(hipGetLastError());
+    // results visible on return (:271 hipDeviceSynchronize)
+    const int rc = pcg_collect(m, relative_tolerance * relative_tolerance, 0, stats);
+    if (trace) {
+        const double t_c = now();
+        fprintf(stderr, "kmcf_pcg_jacobi trace: enqueue %.1f us, wait %.1f us, total %.1f us, device %.1f us\n", t_b - t_a, t_c - t_b,
+                t_c - t_a, stats ? stats->ms_solve * 1e3 : 0.0);
+    }
+    return rc;
 }
 
 namespace {

@@ -128,6 +128,7 @@ extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int ran
     KMCF_HIP(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), 1024 * sizeof(double)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 16 * sizeof(int), hipHostMallocDefault));
+    KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_scal), sizeof(kmcf_scalars), hipHostMallocDefault));
     c->connected = (nranks == 1);
     *out = c;
     return KMCF_OK;
@@ -203,6 +204,7 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_scal) hipHostFree(c->h_scal);
     delete c;
     return KMCF_OK;
 }

@@ -41,6 +41,10 @@ struct kmcf_event_cache {
     const int *sym_key = nullptr;       // neighbour list the symmetry verdict belongs to
     int sym_N = 0;
     bool symmetric = false;
+    // replicated step of a multi-rank group: the neighbour lists of ALL sites, gathered once
+    int *d_neigh_full = nullptr;
+    const int *full_key = nullptr;      // caller's list the gathered copy belongs to
+    int full_N = 0;
 };
 
 void kmcf_event_cache_free(kmcf_comm *c)
@@ -48,7 +52,7 @@ void kmcf_event_cache_free(kmcf_comm *c)
     if (!c || !c->ev_cache) return;
     kmcf_event_cache *w = c->ev_cache;
     void *ptrs[] = {w->d_type, w->d_prob, w->d_tsum, w->d_gsum, w->d_tot, w->d_ij, w->d_aff, w->d_asym,
-                    w->d_u, w->d_totlog, w->d_evlog, w->d_state};
+                    w->d_u, w->d_totlog, w->d_evlog, w->d_state, w->d_neigh_full};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete w;
@@ -460,8 +464,15 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
     KMCF_CHECK(num_layers > 0 && num_layers <= MAX_LAYERS && nn > 0 && freq > 0, KMCF_ERR_ARG, "kmcf_execute_kmc_step: bad sizes");
     KMCF_TRY(kmcf_enter(c));
     hipStream_t st = c->stream;
-    const int P = c->nranks, rank = c->rank;
-    const int count = h_count[rank], start_i = h_displs[rank];
+    // Multi-rank groups: the reference partitions the event list and pays a zero-out pass, an MPI_Allgather, an
+    // MPI_Bcast and two host synchronisations PER EVENT (:423-459; ~1e4 events per 40 nm step).  The site arrays
+    // are replicated on every rank anyway, so here every rank runs the whole step on the whole list: the neighbour
+    // lists are gathered once, the generators are in the same state by contract, and the ranks execute the same
+    // events with no collective and no extra synchronisation at all.  KMCF_EVENTS_PARTITIONED=1 keeps the
+    // reference's scheme.
+    const bool replicate = c->nranks > 1 && !getenv("KMCF_EVENTS_PARTITIONED");
+    const int P = replicate ? 1 : c->nranks, rank = replicate ? 0 : c->rank;
+    const int count = replicate ? N : h_count[rank], start_i = replicate ? 0 : h_displs[rank];
     const size_t M = (size_t)count * nn;
     const int nb = (int)((M + EV_TILE - 1) / EV_TILE);
     const int ng = std::max((nb + EV_GROUP - 1) / EV_GROUP, 1);
@@ -492,6 +503,26 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         }
     }
     kmcf_event_cache *w = c->ev_cache;
+    if (replicate) {
+        if (w->full_key != d_neigh_idx || w->full_N != N) {     // the lists are built once per run (kmc_main.cpp:199)
+            if (w->d_neigh_full) { hipFree(w->d_neigh_full); w->d_neigh_full = nullptr; }
+            KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&w->d_neigh_full), (size_t)N * nn * sizeof(int)));
+            const int R = c->nranks;
+            std::vector<int> cn(R), dn(R);
+            for (int q = 0; q < R; ++q) {
+                KMCF_CHECK((int64_t)h_count[q] * nn < INT32_MAX && (int64_t)h_displs[q] * nn < INT32_MAX, KMCF_ERR_ARG,
+                           "kmcf_execute_kmc_step: neighbour list too large for the int32 gather");
+                cn[q] = h_count[q] * nn; dn[q] = h_displs[q] * nn;
+            }
+            if (h_count[c->rank] > 0)
+                KMCF_HIP(hipMemcpyAsync(w->d_neigh_full + (size_t)dn[c->rank], d_neigh_idx, (size_t)cn[c->rank] * sizeof(int),
+                                        hipMemcpyDeviceToDevice, st));
+            KMCF_TRY(kmcf_comm_allgatherv_int(c, w->d_neigh_full, cn.data(), dn.data()));
+            w->full_key = d_neigh_idx;
+            w->full_N = N;
+        }
+        d_neigh_idx = w->d_neigh_full;
+    }
     unsigned char *d_type = w->d_type;
     double *d_prob = w->d_prob, *d_tsum = w->d_tsum, *d_gsum = w->d_gsum, *d_tot = w->d_tot;
     int *d_ij = w->d_ij, *d_aff = w->d_aff, *d_asym = w->d_asym;

@@ -93,6 +93,7 @@ struct kmcf_comm {
     bool force_collectives = false;     // KMCF_FORCE_COMM: 1-rank group still runs the collectives
     bool connected = false;
     int *h_pinned = nullptr;            // 16 ints pinned host (done/iters read-back)
+    kmcf_scalars *h_scal = nullptr;     // pinned host copy of a solve's scalars (read after the call's one sync)
     // event-step workspace kept between KMC steps (kmcf_execute_kmc_step, kmcf_events.hip)
     struct kmcf_event_cache *ev_cache = nullptr;
 };
@@ -176,6 +177,8 @@ struct kmcf_matrix {
     int64_t n_wcols = 0;               // sum of the tiles' window sizes
     int spmv_wmax = 0;
     int2 *d_tile = nullptr;            // (first row, first window slot) per tile, n_tiles + 1
+    int4 *d_tile4 = nullptr;           // (first row, rows, first window slot, window size) per tile: the coded kernel's view
+    int *d_tbase = nullptr;            // first entry of each tile
     int *d_wcol = nullptr;             // column of each window slot (ascending inside a tile)
     unsigned short *d_idx16 = nullptr; // per nnz: window slot of its column inside the tile (bits 0-9) | value code (10-15)
     // Dictionary-coded values (window kernel only): when every off-diagonal value of the matrix is one of

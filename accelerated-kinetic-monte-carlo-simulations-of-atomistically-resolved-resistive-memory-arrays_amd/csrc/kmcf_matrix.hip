@@ -298,6 +298,29 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     }
     KMCF_TRY(kmcf_spmv_plan(m));
     if (h_val) KMCF_TRY(kmcf_matrix_encode_from_host(m, val_int.data()));
+    // RCCL transport: what every rank sends to a neighbour must be what that neighbour expects, or the grouped
+    // ncclSend / ncclRecv of the first exchange hangs instead of failing (a structurally asymmetric matrix; the
+    // loopback transport checks the same at exchange time).  One small all-gather at build time.
+    if (P > 1 && !c->group && c->connected) {
+        std::vector<int> tab((size_t)2 * P * P, 0), cnt(P, 2 * P), dsp(P);
+        for (int q = 0; q < P; ++q) dsp[q] = 2 * P * q;
+        for (int k = 1; k < nnb; ++k) {
+            tab[(size_t)2 * P * rank + m->neighbours[k]] = (int)m->rows_per_neighbour[k].size();        // sent to q
+            tab[(size_t)2 * P * rank + P + m->neighbours[k]] = (int)m->cols_per_neighbour[k].size();    // expected from q
+        }
+        int *d_tab = nullptr;
+        KMCF_TRY(dev_upload(&d_tab, tab));
+        int rc = kmcf_comm_allgatherv_int(c, d_tab, cnt.data(), dsp.data());
+        if (rc == KMCF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KMCF_ERR_HIP;
+        if (rc == KMCF_OK && hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = KMCF_ERR_HIP;
+        hipFree(d_tab);
+        if (rc != KMCF_OK) return rc;
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b)
+                KMCF_CHECK(tab[(size_t)2 * P * a + b] == tab[(size_t)2 * P * b + P + a], KMCF_ERR_COMM,
+                           "kmcf_matrix_build: rank %d sends %d halo values to rank %d, which expects %d (matrix not structurally symmetric?)",
+                           a, tab[(size_t)2 * P * a + b], b, tab[(size_t)2 * P * b + P + a]);
+    }
     guard.m = nullptr;
     *out = m;
     return KMCF_OK;
@@ -367,7 +390,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,
                         m->d_tile, m->d_wcol, m->d_idx16, m->d_dict, m->d_diagv, m->d_diag_pos, m->d_code_fail,
-                        m->d_long_items, m->d_long_part, m->d_long_ctr};
+                        m->d_long_items, m->d_long_part, m->d_long_ctr, m->d_tile4, m->d_tbase};
         for (void *p : ptrs)
             if (p) hipFree(p);
     }

@@ -217,29 +217,23 @@ struct slot_pack {
     typedef unsigned int type __attribute__((ext_vector_type(U / 2)));   // U 16-bit entries
 };
 
-template <int U, int WQ>
-__device__ __forceinline__ void wcode_issue_loads(const int *__restrict__ wcol, const unsigned short *__restrict__ idx16,
-                                                  int w0, int W, int base, int tid, int (&wc)[WQ],
-                                                  typename slot_pack<U>::type &pk)
-{
-    // Unconditional loads (lanes past the window end re-read its last element; both arrays are padded): a
-    // branch per load would make the compiler drain every outstanding load at the join (s_waitcnt vmcnt(0))
-    // and with it the prefetch.  The slot stream comes as ONE 2U-byte load per lane: the tile's entries are
-    // read from the last 2U-byte boundary at or below its first entry (a tile of the coded plan holds at most
-    // 256*U - U entries, so the block's 256 lanes still cover it); the reduction adds the offset back.
-    const int wl = W > 0 ? W - 1 : 0;
-#pragma unroll
-    for (int q = 0; q < WQ; ++q) wc[q] = __builtin_nontemporal_load(wcol + w0 + min(q * KMCF_BLOCK + tid, wl));
-    const int abase = base & ~(U - 1);
-    pk = __builtin_nontemporal_load(reinterpret_cast<const typename slot_pack<U>::type *>(idx16 + abase) + tid);
-}
-
+// Stages of the pipeline, each one tile iteration apart so that no load waits for another load of the same
+// iteration (the first version fetched tile descriptor -> row_ptr[r0] -> slot stream in a dependent chain and
+// the x gather of a tile inside that tile's own iteration: ~3 exposed memory latencies per tile and block, with
+// ~14 tiles per block the whole kernel time):
+//   A(k): tile descriptor (first row, rows, first window slot, window size) and entry base -- address-only loads
+//   B(k): window map, needs A(k)
+//   C(k): x gather through the window map, slot stream, row data (row_ptr, x, diagonal) -- needs A(k), B(k)
+//   D(k): LDS staging, barrier, row reduction
+// iteration k runs D(k), C(k+1), B(k+2), A(k+3).  Loads are unconditional (clamped addresses): a branch per
+// load would make the compiler drain every outstanding load at the join.  Past the block's last tile the stages
+// reload that last tile.
 template <int U, int WQ, bool DOT, bool SKIP_BOUNDARY>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
-    int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
-    const unsigned short *__restrict__ idx16, const double *__restrict__ x, double *__restrict__ y,
-    const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S,
-    int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
+    int n_tiles, const int4 *__restrict__ tile4, const int *__restrict__ tbase, const int *__restrict__ row_ptr,
+    const int *__restrict__ wcol, const unsigned short *__restrict__ idx16, const double *__restrict__ x,
+    double *__restrict__ y, const unsigned char *__restrict__ is_boundary, double *__restrict__ part,
+    const kmcf_scalars *__restrict__ S, int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
 {
     constexpr int LPR2 = 4, RPP = KMCF_BLOCK / LPR2, SLOT_MASK = (1 << KMCF_SLOT_BITS) - 1, UN = 4;
     typedef typename slot_pack<U>::type pack_t;
@@ -251,100 +245,117 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
     const int tid = threadIdx.x;
     if (tid < 64) sdict[tid] = dict[tid];               // visible after the first tile's barrier
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
-    const int Cx = (n_tiles + 7) >> 3;  // tiles per XCD
+    const int Cx = (n_tiles + 7) >> 3;                  // tiles per XCD
     const int lane = tid % LPR2;
     double dot = 0.0;
-
-    // descriptors and in-flight loads of the tile about to be staged (block-uniform control flow)
-    int g = bi;
-    bool have = g < Cx && xcd * Cx + g < n_tiles;
-    int r0 = 0, r1 = 0, base = 0;
-    int wc[WQ];
-    pack_t pk;
-    // row data of the first pass of that tile (rows past its end re-read its last row): everything the
-    // reduction reads from global memory travels with the prefetch, one tile ahead -- loads return in order,
-    // so a request made after the prefetch would wait behind it
-    int nb = 0, ne = 0;
-    double nxrow = 0.0, ndg = 0.0;
-    if (have) {
-        const int2 t0 = tile[xcd * Cx + g], t1 = tile[xcd * Cx + g + 1];
-        r0 = t0.x; r1 = t1.x;
-        base = row_ptr[r0];
-        wcode_issue_loads<U, WQ>(wcol, idx16, t0.y, t1.y - t0.y, base, tid, wc, pk);
-        const int rc = min(r0 + tid / LPR2, r1 - 1);
-        nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
-    }
-    int buf = 0;
-    while (have) {
-        // entries sit in LDS at their distance from the aligned load start (wcode_issue_loads)
-        const int cr0 = r0, cr1 = r1, cbase = base & ~(U - 1);
-        int rr = cr0 + tid / LPR2;
-        int b = nb - cbase, e = ne - cbase;
-        double xrow = nxrow, dg = ndg;
-        if (rr >= cr1) b = e = 0;
-        double xr[WQ];
+    // this block's tiles: c(k) = xcd Cx + bi + k nb8 for k < nt
+    const int gmax = min(Cx, n_tiles - xcd * Cx);
+    const int nt = gmax > bi ? (gmax - bi + nb8 - 1) / nb8 : 0;
+    if (nt > 0) {
+        const int c_first = xcd * Cx + bi;
+#define KMCF_TILE_OF(k) (c_first + min((k), nt - 1) * nb8)
+        // prologue: A(0..2), B(0..1), C(0)
+        int4 d0 = tile4[KMCF_TILE_OF(0)], d1 = tile4[KMCF_TILE_OF(1)], d2 = tile4[KMCF_TILE_OF(2)];
+        int b0 = tbase[KMCF_TILE_OF(0)], b1 = tbase[KMCF_TILE_OF(1)], b2 = tbase[KMCF_TILE_OF(2)];
+        int wc0[WQ], wc1[WQ];
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) xr[q] = x[wc[q]];
-        sidx_pk[buf][tid] = pk;
-        // prefetch: slot stream, window map and row data of the block's next tile (the current one again at
-        // the end: no branch around the loads, see wcode_issue_loads)
-        const int gn = g + nb8;
-        const bool have_n = gn < Cx && xcd * Cx + gn < n_tiles;
+        for (int q = 0; q < WQ; ++q) {
+            wc0[q] = __builtin_nontemporal_load(wcol + d0.z + min(q * KMCF_BLOCK + tid, max(d0.w - 1, 0)));
+            wc1[q] = __builtin_nontemporal_load(wcol + d1.z + min(q * KMCF_BLOCK + tid, max(d1.w - 1, 0)));
+        }
+        pack_t pk = __builtin_nontemporal_load(reinterpret_cast<const pack_t *>(idx16 + (b0 & ~(U - 1))) + tid);
+        int nb, ne;
+        double nxrow, ndg, xr[WQ];
         {
-            const int cn = xcd * Cx + (have_n ? gn : g);
-            const int2 t0 = tile[cn], t1 = tile[cn + 1];
-            r0 = t0.x; r1 = t1.x;
-            base = row_ptr[r0];
-            wcode_issue_loads<U, WQ>(wcol, idx16, t0.y, t1.y - t0.y, base, tid, wc, pk);
-            const int rc = min(r0 + tid / LPR2, r1 - 1);
+            const int rc = d0.x + min(tid / LPR2, d0.y - 1);
             nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
         }
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) xw[buf][q * KMCF_BLOCK + tid] = xr[q];
-        __syncthreads();
-        const double *xwb = xw[buf];
-        const unsigned short *sib = reinterpret_cast<const unsigned short *>(sidx_pk[buf]);
-        const int passes = (cr1 - cr0 + RPP - 1) / RPP;
-        for (int ps = 0; ps < passes; ++ps) {
-            if (ps > 0) {                                  // tiles of the coded plan hold <= RPP rows per U = 8
-                rr = cr0 + ps * RPP + tid / LPR2;
-                const int rc = min(rr, cr1 - 1);
-                b = row_ptr[rc] - cbase;
-                e = row_ptr[rc + 1] - cbase;
-                xrow = x[rc];
-                dg = diagv[rc];
-                if (rr >= cr1) b = e = 0;
-            }
-            const bool valid = rr < cr1;
-            double s = 0.0;
-            // UN entries per step with independent LDS reads; entries past the row end read as the diagonal
-            // code, whose dictionary value is 0.  The adds stay in entry order: same sums as the other kernels.
-            for (int j0 = b + lane; j0 < e; j0 += LPR2 * UN) {
-                int cc[UN];
+        for (int q = 0; q < WQ; ++q) xr[q] = x[wc0[q]];
+        int buf = 0;
+        for (int k = 0; k < nt; ++k) {
+            // ---- D(k), first half: stage the tile in LDS
+            const int cr0 = d0.x, cr1 = d0.x + d0.y, cbase = b0 & ~(U - 1);
+            int rr = cr0 + tid / LPR2;
+            int b = nb - cbase, e = ne - cbase;
+            double xrow = nxrow, dg = ndg;
+            if (rr >= cr1) b = e = 0;
+            sidx_pk[buf][tid] = pk;
 #pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    const int j = j0 + LPR2 * k;
-                    cc[k] = j < e ? (int)sib[j] : (KMCF_CODE_DIAG << KMCF_SLOT_BITS);
+            for (int q = 0; q < WQ; ++q) xw[buf][q * KMCF_BLOCK + tid] = xr[q];
+            // ---- C(k+1): everything tile k+1 needs is requested now and lands while tile k is reduced
+            pk = __builtin_nontemporal_load(reinterpret_cast<const pack_t *>(idx16 + (b1 & ~(U - 1))) + tid);
+            {
+                const int rc = d1.x + min(tid / LPR2, d1.y - 1);
+                nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
+            }
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) xr[q] = x[wc1[q]];
+            // ---- B(k+2), A(k+3)
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                wc0[q] = wc1[q];
+                wc1[q] = __builtin_nontemporal_load(wcol + d2.z + min(q * KMCF_BLOCK + tid, max(d2.w - 1, 0)));
+            }
+            d0 = d1; b0 = b1;
+            d1 = d2; b1 = b2;
+            d2 = tile4[KMCF_TILE_OF(k + 3)];
+            b2 = tbase[KMCF_TILE_OF(k + 3)];
+            __syncthreads();
+            // ---- D(k), second half: row sums out of LDS
+            const double *xwb = xw[buf];
+            const unsigned short *sib = reinterpret_cast<const unsigned short *>(sidx_pk[buf]);
+            // One pass of the row lanes over <= RPP rows.  Tiles planned for U <= 8 hold at most 8 U <= RPP rows:
+            // a single pass whose row data came with the prefetch.  (With a second pass in the same loop the
+            // compiler must assume xrow / dg may come from that pass's fresh loads and waits for ALL outstanding
+            // loads -- the prefetch of the next tiles included -- before the row's last add.)
+            auto row_pass = [&](int rr_, int b_, int e_, double xrow_, double dg_) {
+                const bool valid = rr_ < cr1;
+                double s = 0.0;
+                // UN entries per step with independent LDS reads; entries past the row end read as the diagonal
+                // code, whose dictionary value is 0.
+                for (int j0 = b_ + lane; j0 < e_; j0 += LPR2 * UN) {
+                    int cc[UN];
+#pragma unroll
+                    for (int q = 0; q < UN; ++q) {
+                        // unconditional LDS read, then a select: a branch per entry (what the compiler makes of a
+                        // guarded read) costs more issue slots than the read itself.  Reads past the row's end
+                        // stay inside the block's LDS (at most 3 LPR2 entries behind a tile of <= 256 U - U
+                        // entries; the second buffer and the dictionary follow) and are discarded by the select.
+                        const int j = j0 + LPR2 * q;
+                        const int raw = (int)sib[j];
+                        cc[q] = j < e_ ? raw : (KMCF_CODE_DIAG << KMCF_SLOT_BITS);
+                    }
+                    double xv[UN], vv[UN];
+#pragma unroll
+                    for (int q = 0; q < UN; ++q) {
+                        xv[q] = xwb[cc[q] & SLOT_MASK];
+                        vv[q] = sdict[cc[q] >> KMCF_SLOT_BITS];
+                    }
+#pragma unroll
+                    for (int q = 0; q < UN; ++q) s = __builtin_fma(vv[q], xv[q], s);     // one rounding per entry
                 }
-                double xv[UN], vv[UN];
-#pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    xv[k] = xwb[cc[k] & SLOT_MASK];
-                    vv[k] = sdict[cc[k] >> KMCF_SLOT_BITS];
+                s = wave_sum_width(s, LPR2);
+                if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr_])) {
+                    s += dg_ * xrow_;
+                    y[rr_] = s;
+                    if (DOT) dot += xrow_ * s;
                 }
-#pragma unroll
-                for (int k = 0; k < UN; ++k) s += vv[k] * xv[k];
+            };
+            row_pass(rr, b, e, xrow, dg);
+            if constexpr (8 * U > RPP) {
+                const int passes = (cr1 - cr0 + RPP - 1) / RPP;
+                for (int ps = 1; ps < passes; ++ps) {
+                    const int r2 = cr0 + ps * RPP + tid / LPR2;
+                    const int rc = min(r2, cr1 - 1);
+                    int b2_ = row_ptr[rc] - cbase, e2_ = row_ptr[rc + 1] - cbase;
+                    if (r2 >= cr1) b2_ = e2_ = 0;
+                    row_pass(r2, b2_, e2_, x[rc], diagv[rc]);
+                }
             }
-            s = wave_sum_width(s, LPR2);
-            if (valid && lane == 0 && !(SKIP_BOUNDARY && is_boundary[rr])) {
-                s += dg * xrow;
-                y[rr] = s;
-                if (DOT) dot += xrow * s;
-            }
+            buf ^= 1;
         }
-        g = gn;
-        have = have_n;
-        buf ^= 1;
+#undef KMCF_TILE_OF
     }
     if (DOT) {
         double t = block_sum_256(dot, lds4);
@@ -540,7 +551,7 @@ void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 #define KMCF_WINDOW_ARGS(isb, part) \
     m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_val, m->d_p, m->d_Ap, isb, part, m->d_S, chk
 #define KMCF_WCODE_ARGS(isb, part) \
-    m->n_tiles, m->d_tile, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_p, m->d_Ap, isb, part, m->d_S, chk, m->d_dict, m->d_diagv
+    m->n_tiles, m->d_tile4, m->d_tbase, m->d_row_ptr, m->d_wcol, m->d_idx16, m->d_p, m->d_Ap, isb, part, m->d_S, chk, m->d_dict, m->d_diagv
 
 template <typename K, typename... A>
 void run_or_query(K kernel, bool launch, int *per_cu, int grid, hipStream_t st, A... args)
@@ -694,6 +705,20 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_wcol), wcol.size() * sizeof(int)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_idx16), idx.size() * sizeof(unsigned short)));
     KMCF_HIP(hipMemcpy(m->d_tile, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    {   // self-contained descriptors for the coded kernel's prefetch pipeline (no dependent loads)
+        std::vector<int4> t4((size_t)nt + 1);
+        std::vector<int> tb((size_t)nt + 1);
+        for (int c = 0; c < nt; ++c) {
+            t4[c] = make_int4(tiles[c].x, tiles[c + 1].x - tiles[c].x, tiles[c].y, tiles[c + 1].y - tiles[c].y);
+            tb[c] = rp[tiles[c].x];
+        }
+        t4[nt] = make_int4(n, 1, 0, 0);
+        tb[nt] = rp[n];
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tile4), t4.size() * sizeof(int4)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tbase), tb.size() * sizeof(int)));
+        KMCF_HIP(hipMemcpy(m->d_tile4, t4.data(), t4.size() * sizeof(int4), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(m->d_tbase, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     KMCF_HIP(hipMemcpy(m->d_wcol, wcol.data(), wcol.size() * sizeof(int), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(m->d_idx16, idx.data(), idx.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     m->n_tiles = nt;
@@ -924,8 +949,10 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     KMCF_TRY(kmcf_halo_exchange_begin(m));
     launch_interior(m, with_dot, skip_if_done);
     KMCF_HIP(hipGetLastError());
+    // the compute stream always waits for the exchange it started: a rank that only SENDS (n_send > 0, no halo
+    // of its own) must not repack d_send_buf while the previous send is still reading it
+    if (m->n_halo > 0 || m->n_send > 0) KMCF_TRY(kmcf_halo_exchange_end(m));
     if (m->n_halo > 0) {
-        KMCF_TRY(kmcf_halo_exchange_end(m));
         if (m->n_boundary_rows > 0) {
             launch_vec_any(m, with_dot, skip_if_done, true);
             KMCF_HIP(hipGetLastError());
@@ -1022,6 +1049,8 @@ extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
     if (m->d_chunk_row) { hipFree(m->d_chunk_row); m->d_chunk_row = nullptr; }
     if (m->d_tile) { hipFree(m->d_tile); m->d_tile = nullptr; }
+    if (m->d_tile4) { hipFree(m->d_tile4); m->d_tile4 = nullptr; }
+    if (m->d_tbase) { hipFree(m->d_tbase); m->d_tbase = nullptr; }
     if (m->d_wcol) { hipFree(m->d_wcol); m->d_wcol = nullptr; }
     if (m->d_idx16) { hipFree(m->d_idx16); m->d_idx16 = nullptr; }
     if (m->d_dict) { hipFree(m->d_dict); m->d_dict = nullptr; }

@@ -73,6 +73,7 @@ SIGNATURES = {
     "kmcf_matrix_get_values": (C.c_int, [_P, _DP]),
     "kmcf_spmv": (C.c_int, [_P, _P, _P]),
     "kmcf_spmv_bench": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "kmcf_spmv_replan": (C.c_int, [_P]),
     "kmcf_comm_bench": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "kmcf_pcg_jacobi": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int, C.c_int, C.POINTER(SolveStats)]),
     "kmcf_solve_sparse_CG_Jacobi": (C.c_int, [_P, _P, _P, C.c_double, C.c_int, C.POINTER(SolveStats)]),

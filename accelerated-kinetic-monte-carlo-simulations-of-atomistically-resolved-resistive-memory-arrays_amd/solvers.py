@@ -564,6 +564,11 @@ class Distributed_matrix:
         """dspmv::gpu_packing_cam (dist_iterative/dist_spmv_gpu_packing.cpp:106-228)."""
         _L.check(self.lib.kmcf_spmv(self.handle, _ptr(p), _ptr(Ap)), "kmcf_spmv")
 
+    def replan(self):
+        """kmcf_spmv_replan: re-plan the SpMV from the KMCF_SPMV_* environment (measurement aid)."""
+        _L.check(self.lib.kmcf_spmv_replan(self.handle), "kmcf_spmv_replan")
+        return self.info()
+
     def spmv_bench(self, reps, with_dot=True):
         ms = C.c_float()
         _L.check(self.lib.kmcf_spmv_bench(self.handle, int(reps), 1 if with_dot else 0, C.byref(ms)),

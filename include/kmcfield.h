@@ -143,6 +143,11 @@ int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap);
  * events on that stream; *ms_total receives the elapsed time. */
 int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms_total);
 
+/* Re-plans the SpMV of an existing matrix from the KMCF_SPMV_* environment (KIND 0 vec / 1 stream (CSR) /
+ * 2 window, CODED 0/1, U, WQ, LPR, LPR2) and re-codes its current values.  Measurement aid: bench.py times
+ * the CSR kernel on the same matrix with it (the `roofline_csr` block); tests compare the kernels. */
+int kmcf_spmv_replan(kmcf_matrix *m);
+
 /* Diagnostic for multi-rank runs (collective: same arguments on every rank):
  * times `reps` repetitions of one piece of a distributed CG iteration on the
  * compute stream -- kind 0: the all-reduce of the 3 fused scalars, 1: the halo

@@ -93,6 +93,13 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P, variant, monk
     # (Chronopoulos-Gear) recurrence multi-rank groups use by default: the same Krylov iterates only in exact
     # arithmetic, so its count is held to +-5 % and its solution to the same bounds as the classic one.
     monkeypatch.setenv("KMCF_CG_VARIANT", variant)
+    # the event step of a multi-rank group: replicated on every rank by default (no collective per event); the
+    # reference's partitioned scheme (kmc_events.cu:423-459) stays behind KMCF_EVENTS_PARTITIONED and is exercised
+    # by the "classic" runs.  Both must select the oracle's events.
+    if variant == "classic":
+        monkeypatch.setenv("KMCF_EVENTS_PARTITIONED", "1")
+    else:
+        monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
     d = dev5
     NL = d["N_contact"]
     ks, A = ref5["ks"], ref5["A"]

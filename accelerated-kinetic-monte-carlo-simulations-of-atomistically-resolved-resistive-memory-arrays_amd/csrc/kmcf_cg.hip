@@ -226,6 +226,7 @@ int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *s
     kmcf_comm *c = m->comm;
     KMCF_HIP(hipStreamSynchronize(c->stream));
     if (c->nranks > 1 || c->force_collectives) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
+    KMCF_TRY(kmcf_p2p_check(c));
     const kmcf_scalars &hS = *c->h_scal;
     if (stats) {
         stats->iterations = hS.iters;

@@ -148,6 +148,43 @@ extern "C" int kmcf_comm_unique_id(void *h_id128)
     return KMCF_OK;
 }
 
+// IPC handles of the windows all-gathered through the RCCL communicator, peers opened, then a self-test
+static int p2p_bootstrap_over_rccl(kmcf_comm *c)
+{
+    const int P = c->nranks;
+    std::vector<char> mine(KMCF_P2P_HANDLE_BYTES), all((size_t)P * KMCF_P2P_HANDLE_BYTES);
+    KMCF_TRY(kmcf_comm_p2p_export(c, mine.data()));
+    int *d_h = nullptr;
+    const int wi = KMCF_P2P_HANDLE_BYTES / 4;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_h), all.size()));
+    KMCF_HIP(hipMemcpy(reinterpret_cast<char *>(d_h) + (size_t)c->rank * KMCF_P2P_HANDLE_BYTES, mine.data(), mine.size(), hipMemcpyHostToDevice));
+    std::vector<int> cnt(P, wi), dsp(P);
+    for (int q = 0; q < P; ++q) dsp[q] = q * wi;
+    int rc = kmcf_comm_allgatherv_int(c, d_h, cnt.data(), dsp.data());        // over RCCL: p2p is not active yet
+    if (rc == KMCF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KMCF_ERR_HIP;
+    if (rc == KMCF_OK && hipMemcpy(all.data(), d_h, all.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = KMCF_ERR_HIP;
+    hipFree(d_h);
+    if (rc != KMCF_OK) return rc;
+    KMCF_TRY(kmcf_comm_p2p_import(c, all.data()));
+    // self-test: sums of (rank + 1) * i over a few rounds, both parities
+    double *d_t = nullptr;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_t), 4 * sizeof(double)));
+    for (int round = 1; round <= 4 && rc == KMCF_OK; ++round) {
+        double h[3] = {(c->rank + 1.0) * round, 1.0, -0.5 * c->rank}, want[3] = {0.5 * P * (P + 1.0) * round, (double)P, -0.25 * P * (P - 1.0)};
+        if (hipMemcpy(d_t, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { rc = KMCF_ERR_HIP; break; }
+        rc = kmcf_p2p_allreduce(c, d_t, 3);
+        if (rc == KMCF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KMCF_ERR_HIP;
+        if (rc == KMCF_OK) rc = kmcf_p2p_check(c);
+        if (rc == KMCF_OK && hipMemcpy(h, d_t, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = KMCF_ERR_HIP;
+        if (rc == KMCF_OK && (h[0] != want[0] || h[1] != want[1] || h[2] != want[2])) {
+            kmcf_set_error("p2p self-test: all-reduce gave %g %g %g, expected %g %g %g", h[0], h[1], h[2], want[0], want[1], want[2]);
+            rc = KMCF_ERR_COMM;
+        }
+    }
+    hipFree(d_t);
+    return rc;
+}
+
 extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
 {
     KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_connect: null comm");
@@ -157,6 +194,11 @@ extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
     // every collective of the multi-rank code path (all-reduce of the dots, gathers)
     const bool force = getenv("KMCF_FORCE_COMM") != nullptr;
     if (c->nranks == 1 && !force) { c->connected = true; return KMCF_OK; }
+    if (c->nranks > 1 && !h_id128 && !force) {
+        // no RCCL id: the group will run on the peer-to-peer transport alone; connected once
+        // kmcf_comm_p2p_export / kmcf_comm_p2p_import have mapped the peers' windows
+        return KMCF_OK;
+    }
     KMCF_TRY(load_rccl());
     KMCF_HIP(hipSetDevice(c->device));
     ncclUniqueId id[2];
@@ -174,6 +216,19 @@ extern "C" int kmcf_comm_connect(kmcf_comm *c, const void *h_id128)
     c->nccl_red = comm;
     c->force_collectives = force;
     c->connected = true;
+    // KMCF_TRANSPORT=p2p|auto: map the peers' windows (IPC handles all-gathered over RCCL) and run the exchanges of
+    // the CG loop over them; RCCL stays connected as the fallback.  "auto" keeps RCCL if the set-up or a short
+    // self-test (all-reduces of known values through the windows) fails.
+    const char *tr = getenv("KMCF_TRANSPORT");
+    if (c->nranks > 1 && tr && (strcmp(tr, "p2p") == 0 || strcmp(tr, "auto") == 0)) {
+        const bool must = strcmp(tr, "p2p") == 0;
+        int rc = p2p_bootstrap_over_rccl(c);
+        if (rc != KMCF_OK) {
+            kmcf_p2p_destroy(c);
+            if (must) return rc;
+            fprintf(stderr, "kmcfield: p2p transport unavailable (%s); using RCCL\n", kmcf_last_error());
+        }
+    }
     return KMCF_OK;
 }
 
@@ -191,6 +246,7 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
     kmcf_event_cache_free(c);
+    kmcf_p2p_destroy(c);
     if (c->nccl) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
     if (c->nccl_red) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_red));
     if (c->ev_packed) hipEventDestroy(c->ev_packed);
@@ -346,12 +402,33 @@ extern "C" int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks
         out[r]->group = g;
         out[r]->connected = true;
     }
+    // KMCF_TRANSPORT=p2p: the members drive the device-side peer-to-peer protocol (kmcf_p2p.hip) on each other's
+    // windows -- same kernels, flags and sequence numbers as between processes, plain pointers instead of IPC
+    // handles.  The ranks' kernels wait for each other ON the GPU, so their streams must map to different hardware
+    // queues (GPU_MAX_HW_QUEUES >= 2 * nranks, set before HIP initialises; tests/conftest.py does).
+    const char *tr = getenv("KMCF_TRANSPORT");
+    if (tr && strcmp(tr, "p2p") == 0 && nranks > 1) {
+        std::vector<char *> bases((size_t)nranks);
+        for (int r = 0; r < nranks; ++r) {
+            KMCF_TRY(kmcf_p2p_create(out[r]));
+            bases[r] = kmcf_p2p_window(out[r]);
+        }
+        for (int r = 0; r < nranks; ++r) KMCF_TRY(kmcf_p2p_set_peers_direct(out[r], bases.data()));
+    }
     return KMCF_OK;
+}
+
+extern "C" const char *kmcf_comm_transport(const kmcf_comm *c)
+{
+    if (!c || c->nranks == 1) return "single";
+    if (c->p2p_active) return c->group ? "p2p (in-process group)" : (c->nccl ? "p2p (bootstrapped over rccl)" : "p2p");
+    return c->group ? "loopback" : "rccl";
 }
 
 // Sum `count` doubles in place over all ranks, on the compute stream, device resident.
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 {
+    if (c->p2p_active && c->nranks > 1) return kmcf_p2p_allreduce(c, d_buf, count);
     if (c->group) return c->group->nranks > 1 ? loopback_allreduce(c, d_buf, count) : KMCF_OK;
     if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
     KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
@@ -367,6 +444,7 @@ int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 int kmcf_comm_send_recv_halo(kmcf_matrix *m)
 {
     kmcf_comm *c = m->comm;
+    if (c->p2p_active && c->nranks > 1) return kmcf_p2p_halo_exchange(m);
     if (c->group) return c->group->nranks > 1 ? loopback_halo(m) : KMCF_OK;   // every rank takes part, neighbours or not
     if (m->number_of_neighbours <= 1) return KMCF_OK;
     KMCF_CHECK(c->nccl, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
@@ -387,6 +465,16 @@ int kmcf_comm_send_recv_halo(kmcf_matrix *m)
 template <typename T>
 static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int *displs, ncclDataType_t dt)
 {
+    // gathers that fit the window's staging area go peer to peer; the rare big ones (the neighbour lists of the
+    // replicated event step, once per run) take the transport underneath
+    if (c->p2p_active && c->nranks > 1 &&
+        kmcf_p2p_fits(c, ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(T)))
+        return kmcf_p2p_allgatherv(c, d_buf, counts, displs, sizeof(T));
+    if (c->p2p_active && c->nranks > 1 && !c->group && !c->nccl_red) {
+        kmcf_set_error("all-gather of %zu bytes exceeds the p2p staging area and no other transport is connected (KMCF_P2P_WINDOW_MB)",
+                       ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(T));
+        return KMCF_ERR_NOMEM;
+    }
     if (c->group) return c->group->nranks > 1 ? loopback_allgatherv(c, d_buf, counts, displs, sizeof(T)) : KMCF_OK;
     if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
     KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");

@@ -74,8 +74,13 @@ struct kmcf_group {
     int refs = 0;
 };
 
+struct kmcf_p2p;        // peer-to-peer transport of a communicator (kmcf_p2p.hip)
+struct kmcf_p2p_halo;   // ... and the halo protocol state of one matrix
+
 struct kmcf_comm {
     kmcf_group *group = nullptr;        // loopback transport (nullptr: RCCL)
+    kmcf_p2p *p2p = nullptr;            // mapped peer windows; used for the exchanges while p2p_active
+    bool p2p_active = false;
     int device = 0;
     int nranks = 1;
     int rank = 0;
@@ -118,6 +123,7 @@ struct kmcf_matrix {
     double *d_long_part = nullptr;     // one partial per chunk
     unsigned int *d_long_ctr = nullptr;
     kmcf_subop *sub = nullptr;         // optional: y[sub rows] += S x_sub after the CSR part (T matrix)
+    kmcf_p2p_halo *p2p = nullptr;      // halo landing zone / flags in the peer windows (p2p transport)
     int row0 = 0;                 // displs[rank]
     int64_t nnz = 0;
     std::vector<int> counts, displs;
@@ -278,6 +284,19 @@ int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count);
 int kmcf_comm_send_recv_halo(kmcf_matrix *m);
 int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);
 int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs);
+// p2p.hip
+int kmcf_p2p_create(kmcf_comm *c);
+int kmcf_p2p_destroy(kmcf_comm *c);
+int kmcf_p2p_set_peers_direct(kmcf_comm *c, char *const *bases);
+char *kmcf_p2p_window(kmcf_comm *c);
+bool kmcf_p2p_fits(kmcf_comm *c, size_t gather_bytes);
+int kmcf_p2p_check(kmcf_comm *c);          // KMCF_ERR_COMM if a bounded wait expired (call after a synchronisation)
+int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count);
+int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem);
+int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8);
+int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8);
+void kmcf_p2p_matrix_free(kmcf_matrix *m);
+int kmcf_p2p_halo_exchange(kmcf_matrix *m);
 // matrix.hip
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
                       const int *h_row_ptr, const int *h_col_global, const double *h_val,

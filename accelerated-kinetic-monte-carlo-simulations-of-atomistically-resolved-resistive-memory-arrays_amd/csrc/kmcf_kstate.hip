@@ -485,7 +485,7 @@ extern "C" int kmcf_update_charge(kmcf_comm *c, const int *d_site_element, int *
     }
     KMCF_TRY(kmcf_comm_allgatherv_int(c, d_site_charge, h_count, h_displ));   // MPI_Allgatherv, :82-83
     KMCF_HIP(hipStreamSynchronize(c->stream));                                   // hipDeviceSynchronize, :80
-    return KMCF_OK;
+    return kmcf_p2p_check(c);
 }
 
 #define KMCF_ASM_ARGS(VL, VR)                                                                                          \
@@ -665,7 +665,7 @@ extern "C" int kmcf_sum_and_gather_potential(kmcf_kstate *k, double *d_site_pote
     sum_ab_kernel<<<grid1d(N), KMCF_BLOCK, 0, c->stream>>>(d_site_potential_charge, d_site_potential_boundary, N);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(c->stream));
-    return KMCF_OK;
+    return kmcf_p2p_check(c);
 }
 
 extern "C" int kmcf_update_temperature_global(kmcf_comm *c, const double *d_site_power, double *d_T_bg, int N,

@@ -298,28 +298,45 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     }
     KMCF_TRY(kmcf_spmv_plan(m));
     if (h_val) KMCF_TRY(kmcf_matrix_encode_from_host(m, val_int.data()));
-    // RCCL transport: what every rank sends to a neighbour must be what that neighbour expects, or the grouped
-    // ncclSend / ncclRecv of the first exchange hangs instead of failing (a structurally asymmetric matrix; the
-    // loopback transport checks the same at exchange time).  One small all-gather at build time.
-    if (P > 1 && !c->group && c->connected) {
-        std::vector<int> tab((size_t)2 * P * P, 0), cnt(P, 2 * P), dsp(P);
-        for (int q = 0; q < P; ++q) dsp[q] = 2 * P * q;
+    // What every rank sends to a neighbour must be what that neighbour expects, or the grouped ncclSend / ncclRecv
+    // of the first exchange hangs instead of failing (a structurally asymmetric matrix; the host loopback transport
+    // checks the same at exchange time).  One small all-gather at build time; with the peer-to-peer transport the
+    // same table tells every sender where in the receiver's window its data and its flag go.
+    if (P > 1 && c->connected && (c->p2p_active || !c->group)) {
+        const int W = 4 * P;                      // per rank: sent to q | expected from q | landing offset | flag offset (8-byte units)
+        std::vector<int> tab((size_t)W * P, 0), cnt(P, W), dsp(P);
+        for (int q = 0; q < P; ++q) dsp[q] = W * q;
+        int land8 = 0, flag8 = 0;
+        if (c->p2p_active) KMCF_TRY(kmcf_p2p_matrix_alloc(m, &land8, &flag8));
         for (int k = 1; k < nnb; ++k) {
-            tab[(size_t)2 * P * rank + m->neighbours[k]] = (int)m->rows_per_neighbour[k].size();        // sent to q
-            tab[(size_t)2 * P * rank + P + m->neighbours[k]] = (int)m->cols_per_neighbour[k].size();    // expected from q
+            const int q = m->neighbours[k];
+            tab[(size_t)W * rank + q] = (int)m->rows_per_neighbour[k].size();
+            tab[(size_t)W * rank + P + q] = (int)m->cols_per_neighbour[k].size();
+            tab[(size_t)W * rank + 2 * P + q] = land8 + m->halo_offset[k];       // neighbour q's values land at its halo slots
+            tab[(size_t)W * rank + 3 * P + q] = flag8 + (k - 1);
         }
         int *d_tab = nullptr;
         KMCF_TRY(dev_upload(&d_tab, tab));
         int rc = kmcf_comm_allgatherv_int(c, d_tab, cnt.data(), dsp.data());
         if (rc == KMCF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KMCF_ERR_HIP;
+        if (rc == KMCF_OK && c->p2p_active) rc = kmcf_p2p_check(c);
         if (rc == KMCF_OK && hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = KMCF_ERR_HIP;
         hipFree(d_tab);
         if (rc != KMCF_OK) return rc;
         for (int a = 0; a < P; ++a)
             for (int b = 0; b < P; ++b)
-                KMCF_CHECK(tab[(size_t)2 * P * a + b] == tab[(size_t)2 * P * b + P + a], KMCF_ERR_COMM,
+                KMCF_CHECK(tab[(size_t)W * a + b] == tab[(size_t)W * b + P + a], KMCF_ERR_COMM,
                            "kmcf_matrix_build: rank %d sends %d halo values to rank %d, which expects %d (matrix not structurally symmetric?)",
-                           a, tab[(size_t)2 * P * a + b], b, tab[(size_t)2 * P * b + P + a]);
+                           a, tab[(size_t)W * a + b], b, tab[(size_t)W * b + P + a]);
+        if (c->p2p_active) {
+            std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0);
+            for (int k = 1; k < nnb; ++k) {
+                const int q = m->neighbours[k];
+                r_land[k] = tab[(size_t)W * q + 2 * P + rank];
+                r_flag[k] = tab[(size_t)W * q + 3 * P + rank];
+            }
+            KMCF_TRY(kmcf_p2p_matrix_connect(m, r_land, r_flag));
+        }
     }
     guard.m = nullptr;
     *out = m;
@@ -386,6 +403,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         hipSetDevice(m->comm->device);
         hipStreamSynchronize(m->comm->stream);
         hipStreamSynchronize(m->comm->comm_stream);
+        kmcf_p2p_matrix_free(m);
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,

@@ -920,9 +920,9 @@ int kmcf_halo_exchange_begin(kmcf_matrix *m)
 {
     kmcf_comm *c = m->comm;
     // in a loopback group every rank takes part in the (host-synchronous) exchange, neighbours or not
-    const bool loopback = c->group && c->group->nranks > 1;
+    const bool loopback = c->group && c->group->nranks > 1 && !c->p2p_active;
     if (m->number_of_neighbours <= 1 && !loopback) return KMCF_OK;
-    if (m->n_send > 0) {
+    if (m->n_send > 0 && !c->p2p_active) {          // (the peer-to-peer transport packs inside its put kernel)
         const int grid = grid_for(m->n_send, KMCF_BLOCK);
         pack_kernel<<<grid, KMCF_BLOCK, 0, c->stream>>>(m->d_send_buf, m->d_p, m->d_send_idx, m->n_send, m->d_S, 0);
         KMCF_HIP(hipGetLastError());
@@ -995,7 +995,7 @@ extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
     KMCF_TRY(kmcf_spmv_device(m, false, false));
     KMCF_TRY(kmcf_vec_out(m, d_Ap, m->d_Ap));
     KMCF_HIP(hipStreamSynchronize(c->stream));
-    return KMCF_OK;
+    return kmcf_p2p_check(c);
 }
 
 extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms_total)

@@ -1120,6 +1120,7 @@ extern "C" int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_elemen
         KMCF_HIP(hipGetLastError());
     }
     KMCF_HIP(hipStreamSynchronize(st));
+    KMCF_TRY(kmcf_p2p_check(c));
     if (imacro) *imacro = h_im;
     if (stats) {
         float ms = 0.f;

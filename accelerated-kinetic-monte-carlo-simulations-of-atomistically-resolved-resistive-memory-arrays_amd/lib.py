@@ -62,6 +62,9 @@ SIGNATURES = {
     "kmcf_comm_sync": (C.c_int, [_P]),
     "kmcf_comm_stream": (_P, [_P]),
     "kmcf_comm_set_caller_stream": (C.c_int, [_P, _P]),
+    "kmcf_comm_p2p_export": (C.c_int, [_P, _P]),
+    "kmcf_comm_p2p_import": (C.c_int, [_P, _P]),
+    "kmcf_comm_transport": (C.c_char_p, [_P]),
     "kmcf_partition": (C.c_int, [C.c_int, C.c_int, _IP, _IP]),
     "kmcf_matrix_create_csr": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _DP, C.POINTER(_P)]),
     "kmcf_matrix_destroy": (C.c_int, [_P]),

@@ -90,6 +90,23 @@ class KMC_comm:
         raw = bytes(t.cpu().tolist())
         _L.check(self.lib.kmcf_comm_connect(self.handle, C.create_string_buffer(raw, len(raw))), "kmcf_comm_connect")
 
+    def connect_p2p(self, dist):
+        """Bootstrap the peer-to-peer transport WITHOUT RCCL (kmcf_comm_p2p_export / _import): every rank exports
+        the IPC handle of its window, the host program all-gathers them (here: torch.distributed, any backend), every
+        rank maps its peers.  Used where RCCL cannot run (several ranks on one GPU) and by tests."""
+        _L.check(self.lib.kmcf_comm_connect(self.handle, None), "kmcf_comm_connect")
+        nb = 64   # KMCF_P2P_HANDLE_BYTES
+        buf = (C.c_char * nb)()
+        _L.check(self.lib.kmcf_comm_p2p_export(self.handle, buf), "kmcf_comm_p2p_export")
+        mine = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+        parts = [torch.zeros(nb, dtype=torch.uint8) for _ in range(self.size_K)]
+        dist.all_gather(parts, mine)
+        raw = b"".join(bytes(t.tolist()) for t in parts)
+        _L.check(self.lib.kmcf_comm_p2p_import(self.handle, C.create_string_buffer(raw, len(raw))), "kmcf_comm_p2p_import")
+
+    def transport(self):
+        return self.lib.kmcf_comm_transport(self.handle).decode()
+
     def sync(self):
         _L.check(self.lib.kmcf_comm_sync(self.handle), "kmcf_comm_sync")
 

@@ -70,6 +70,16 @@ int kmcf_comm_destroy(kmcf_comm *c);
  * device copies; exists because RCCL refuses two ranks on one GPU, so that the multi-rank logic
  * (halo maps, boundary pass, reductions) can be exercised on a 1-GPU box.  Not a performance path. */
 int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks);
+/* Peer-to-peer transport (csrc/kmcf_p2p.hip): the CG's all-reduces and halo exchanges done by kernels over
+ * IPC-mapped peer windows instead of one RCCL call each.  KMCF_TRANSPORT=p2p|auto makes kmcf_comm_connect set it up
+ * over the RCCL communicator (auto: RCCL stays if set-up or self-test fail).  Without RCCL (kmcf_comm_connect with a
+ * NULL id on a multi-rank group): every rank calls kmcf_comm_p2p_export, the host program all-gathers the
+ * KMCF_P2P_HANDLE_BYTES of every rank in rank order, every rank calls kmcf_comm_p2p_import.  All waits are bounded
+ * (KMCF_P2P_TIMEOUT_MS, default 2000): a peer that never arrives yields KMCF_ERR_COMM, not a hang. */
+#define KMCF_P2P_HANDLE_BYTES 64
+int kmcf_comm_p2p_export(kmcf_comm *c, void *h_handle /* KMCF_P2P_HANDLE_BYTES */);
+int kmcf_comm_p2p_import(kmcf_comm *c, const void *h_handles /* nranks x KMCF_P2P_HANDLE_BYTES */);
+const char *kmcf_comm_transport(const kmcf_comm *c);   /* "single", "loopback", "rccl", "p2p ..." */
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
 /* Declares the hipStream_t the caller queues its own device work on (NULL = legacy null

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# In-process rank groups that drive the device-side peer-to-peer protocol (KMCF_TRANSPORT=p2p) wait for each
+# other ON the GPU: their streams must not share a hardware queue.  Read by the HIP runtime when it initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(km, d, P, ref_charge):
+def _run_ranks(km, d, P, ref_charge, expect_transport="loopback"):
     import torch
     S = km.solvers
     NL = d["N_contact"]
@@ -29,6 +29,7 @@ def _run_ranks(km, d, P, ref_charge):
             torch.cuda.set_device(0)
             comm = comms[r]
             comm.connect()
+            assert comm.transport() == expect_transport, comm.transport()
             buf = S.GPUBuffers(d["N"], d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"],
                                d["k"], d["lattice"], d["metals"])
             S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
@@ -154,6 +155,26 @@ def test_multirank_solve_matches_oracle(km, oracle, dev5, ref5, P, variant, monk
         assert o["ev_n"] == n_o and np.array_equal(o["ev_log"], log_o)
         assert o["ev_t"] == pytest.approx(t_o, rel=1e-12)
         assert np.array_equal(o["el_after"], el_o) and np.array_equal(o["ch_after"], ch_o)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_p2p_transport_in_process_matches_loopback_bit_for_bit(km, oracle, dev5, ref5, P, monkeypatch):
+    """The device-side peer-to-peer protocol (csrc/kmcf_p2p.hip: puts into the neighbours' windows, sequence flags,
+    bounded waits, rank-ordered sums) driven by the P members of an in-process group, against the host-synchronous
+    loopback transport: same partition, same kernels, so charges, solution, iteration count and events must be
+    IDENTICAL, bit for bit (both transports add the ranks' partial dot products in rank order)."""
+    monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
+    monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
+    monkeypatch.delenv("KMCF_TRANSPORT", raising=False)
+    base = _run_ranks(km, dev5, P, ref5["charge"])
+    monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+    monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")       # ranks are Python threads here: their host-side set-up can be seconds apart
+    p2p = _run_ranks(km, dev5, P, ref5["charge"], expect_transport="p2p (in-process group)")
+    for a, b in zip(base, p2p):
+        assert np.array_equal(a["charge"], b["charge"])
+        assert a["st"]["iterations"] == b["st"]["iterations"] and a["st"]["relres"] == b["st"]["relres"]
+        assert np.array_equal(a["Ap"], b["Ap"]) and np.array_equal(a["v"], b["v"]) and np.array_equal(a["tot2"], b["tot2"])
+        assert a["ev_n"] == b["ev_n"] and np.array_equal(a["ev_log"], b["ev_log"]) and a["ev_t"] == b["ev_t"]
 
 
 @pytest.mark.parametrize("n,P", [(10, 4), (3, 4), (2000, 3)])

@@ -418,6 +418,21 @@ extern "C" int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks
     return KMCF_OK;
 }
 
+extern "C" int kmcf_comm_select_transport(kmcf_comm *c, int use_p2p)
+{
+    KMCF_CHECK(c, KMCF_ERR_ARG, "kmcf_comm_select_transport: null comm");
+    if (c->nranks == 1) return KMCF_OK;
+    if (use_p2p) {
+        KMCF_CHECK(c->p2p != nullptr, KMCF_ERR_STATE, "kmcf_comm_select_transport: the peer-to-peer transport was not set up");
+        KMCF_TRY(kmcf_p2p_check(c));
+        c->p2p_active = true;
+    } else {
+        KMCF_CHECK(c->group || c->nccl_red, KMCF_ERR_STATE, "kmcf_comm_select_transport: no other transport is connected");
+        c->p2p_active = false;
+    }
+    return KMCF_OK;
+}
+
 extern "C" const char *kmcf_comm_transport(const kmcf_comm *c)
 {
     if (!c || c->nranks == 1) return "single";

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline iterations (0 = auto, ~10-30 s)")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "p2p", "p2p-only"],
+                    help="multi-rank data path: auto = peer-to-peer windows if they come up, else RCCL; p2p-only = no RCCL at "
+                         "all (rehearsal of N ranks on fewer GPUs, where RCCL refuses to run)")
     args = ap.parse_args()
 
     import numpy as np
@@ -46,11 +49,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path"
+    if args.transport == "p2p-only" and torch.cuda.device_count() <= local_rank:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        # gloo only carries the 128-byte RCCL bootstrap id, barriers and the max-over-ranks
-        # timing; the data path (halos, dot products) is RCCL inside libkmcfield
+        # gloo only carries the 256-byte RCCL bootstrap id, barriers and the max-over-ranks
+        # timing; the data path (halos, dot products) is inside libkmcfield: RCCL, and -- KMCF_TRANSPORT=auto --
+        # the peer-to-peer transport over IPC-mapped windows when its set-up and self-test succeed
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.transport in ("auto", "rccl", "p2p"):
+            os.environ.setdefault("KMCF_TRANSPORT", args.transport)
 
     # ---- workload (identical on every rank; deterministic generator) ----------------------
     t_gen = time.time()
@@ -64,7 +72,10 @@ def main():
     NL = d["N_contact"]
     n_if = d["N"] - 2 * NL
     comm = S.KMC_comm(n_if, d["N"] + 1, d["N"], d["N"], rank=rank, size=world, device=local_rank)
-    comm.connect(dist if world > 1 else None)
+    if world > 1 and args.transport == "p2p-only":
+        comm.connect_p2p(dist)
+    else:
+        comm.connect(dist if world > 1 else None)
     buf = S.GPUBuffers(d["N"], d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"], d["k"],
                        d["lattice"], d["metals"], device=local_rank)
     S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
@@ -103,20 +114,40 @@ def main():
 
     # ---- warmup + timed CG iterations -----------------------------------------------------
     tol = 1e-14 * n_if
-    r, x, dinv = fresh_vectors()
-    if args.warmup > 0:
-        S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=args.warmup)
-    r, x, dinv = fresh_vectors()
-    barrier()
-    t0 = time.perf_counter()
-    st = S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert st["iterations"] == args.steps, st
-    el = torch.tensor([elapsed], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+
+    def timed_solve(steps, warmup):
+        r, x, dinv = fresh_vectors()
+        if warmup > 0:
+            S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=warmup)
+        r, x, dinv = fresh_vectors()
+        barrier()
+        t0 = time.perf_counter()
+        st = S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=steps)
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        assert st["iterations"] == steps, st
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), st
+
+    # Multi-rank groups with both transports up: a short trial solve on each, the faster one runs the timed region
+    # (rank 0 decides).  A transport that fails its trial (a bounded wait of the peer-to-peer protocol expiring on
+    # every rank) is reported and not used.
+    transports = None
+    if world > 1 and comm.transport() == "p2p (bootstrapped over rccl)":
+        transports = {}
+        for name, use in (("rccl", 0), ("p2p", 1)):
+            try:
+                comm.select_transport(use)
+                t_trial, _ = timed_solve(min(args.steps, 20), 3)
+                transports[name] = {"trial_ms_per_step": round(t_trial * 1e3 / min(args.steps, 20), 5)}
+            except km.lib.KmcfError as e:
+                transports[name] = {"error": str(e)[:200]}
+        ok = {k: v["trial_ms_per_step"] for k, v in transports.items() if "trial_ms_per_step" in v}
+        pick = torch.tensor([1 if ("p2p" in ok and ok["p2p"] <= ok.get("rccl", 1e30)) else 0])
+        dist.broadcast(pick, src=0)
+        comm.select_transport(int(pick.item()))
+    elapsed, st = timed_solve(args.steps, args.warmup)
 
     # ---- roofline of the dominant kernel: CSR SpMV (+ fused p.Ap) -------------------------
     # HIP events on the library's compute stream (kmcf_spmv_bench), this rank's rows
@@ -184,15 +215,30 @@ def main():
             mat.replan()
             S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])      # the assembly writes the value codes again
 
-    # multi-rank diagnostic: the pieces of one distributed iteration timed separately (rank 0's clock)
+    # multi-rank diagnostic: the pieces of one distributed iteration timed separately (rank 0's clock), on every
+    # transport that is up
     diag = None
     if world > 1:
         reps = 200
-        diag = {}
-        for kind, key in ((0, "allreduce3_us"), (1, "halo_exchange_us"), (2, "spmv_kernels_us")):
-            mat.comm_bench(kind, 10)
-            diag[key] = round(mat.comm_bench(kind, reps) * 1e3 / reps, 2)
-        diag["cg_variant"] = os.environ.get("KMCF_CG_VARIANT", "cg1r")
+        diag = {"transport_used": comm.transport(), "cg_variant": os.environ.get("KMCF_CG_VARIANT", "cg1r")}
+        if transports is not None:
+            diag["transports"] = transports
+        used_p2p = comm.transport().startswith("p2p")
+        for name, use in ((("rccl", 0), ("p2p", 1)) if transports is not None else ((comm.transport(), None),)):
+            if transports is not None and "error" in transports.get(name, {}):
+                continue
+            try:
+                if use is not None:
+                    comm.select_transport(use)
+                d_t = {}
+                for kind, key in ((0, "allreduce3_us"), (1, "halo_exchange_us"), (2, "spmv_kernels_us")):
+                    mat.comm_bench(kind, 10)
+                    d_t[key] = round(mat.comm_bench(kind, reps) * 1e3 / reps, 2)
+                diag[name] = d_t
+            except km.lib.KmcfError as e:
+                diag[name] = {"error": str(e)[:200]}
+        if transports is not None:
+            comm.select_transport(1 if used_p2p else 0)
 
     # HBM traffic of that kernel from rocprofv3 PMC runs (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # corrections applied by tools/pmc_summary.py); measured offline on this workload, committed under
@@ -239,7 +285,7 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / args.steps, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": d["name"], "rows": n_if, "nnz": nnz_tot, "sites": d["N"],
-                       "partition": "1-D block rows x %d" % world, "solver": "jacobi-pcg fixed %d iterations" % args.steps,
+                       "partition": "1-D block rows x %d" % world, "transport": comm.transport(), "solver": "jacobi-pcg fixed %d iterations" % args.steps,
                        "halo_cols_rank0": info["halo_cols"], "neighbours_rank0": info["number_of_neighbours"],
                        "setup_s": round(t_setup, 2), "device_ms_cg": round(st["ms_solve"], 3)},
             "roofline": roofline,

@@ -80,6 +80,10 @@ int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks);
 int kmcf_comm_p2p_export(kmcf_comm *c, void *h_handle /* KMCF_P2P_HANDLE_BYTES */);
 int kmcf_comm_p2p_import(kmcf_comm *c, const void *h_handles /* nranks x KMCF_P2P_HANDLE_BYTES */);
 const char *kmcf_comm_transport(const kmcf_comm *c);   /* "single", "loopback", "rccl", "p2p ..." */
+/* Switch a group that has BOTH transports up (KMCF_TRANSPORT=p2p|auto over RCCL, or an in-process group) between
+ * them; collective (every rank, same value), between solves.  Matrices built while the peer-to-peer transport was
+ * active work on either. */
+int kmcf_comm_select_transport(kmcf_comm *c, int use_p2p);
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
 /* Declares the hipStream_t the caller queues its own device work on (NULL = legacy null

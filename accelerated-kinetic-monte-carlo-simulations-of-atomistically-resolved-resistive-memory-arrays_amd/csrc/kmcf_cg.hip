@@ -461,7 +461,14 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             const int k = launched + i + 1;
             const int parity = k & 1, first = (k == 1) ? 1 : 0;
             KMCF_TRY(kmcf_spmv_device(m, true, true));                 // w = A z, delta partials
-            if (multi) {
+            if (multi && c->p2p_active && c->nranks > 1) {
+                // finalize + exchange in one 1-block kernel (the b.b partials only count in the first iteration:
+                // later ones re-send stale ones, which nobody reads)
+                const kmcf_part4 parts[3] = {{{pg_loc.p[0], pg_loc.p[1], pg_loc.p[2], pg_loc.p[3]}, {pg_loc.n[0], pg_loc.n[1], pg_loc.n[2], pg_loc.n[3]}},
+                                             {{pd_loc.p[0], pd_loc.p[1], pd_loc.p[2], pd_loc.p[3]}, {pd_loc.n[0], pd_loc.n[1], pd_loc.n[2], pd_loc.n[3]}},
+                                             {{pb_loc.p[0], pb_loc.p[1], pb_loc.p[2], pb_loc.p[3]}, {pb_loc.n[0], pb_loc.n[1], pb_loc.n[2], pb_loc.n[3]}}};
+                KMCF_TRY(kmcf_p2p_allreduce_parts(c, parts, 3, S, 1));
+            } else if (multi) {
                 cg1_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(pg_loc, pd_loc, pb_loc, first, S);
                 KMCF_HIP(hipGetLastError());
                 KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 3));

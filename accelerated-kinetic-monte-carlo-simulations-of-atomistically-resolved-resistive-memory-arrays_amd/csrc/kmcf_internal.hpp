@@ -260,7 +260,8 @@ struct kmcf_subop {
 int kmcf_spmv_plan(kmcf_matrix *m);
 // Ap = A*p on m->d_p (already holding local p), writes m->d_Ap and pAp partials.
 int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done);
-// the four p.Ap partial segments the last SpMV wrote (interior, boundary, long rows, sub-block)
+// up to four arrays of per-block partial sums (an SpMV writes one per pass: interior rows, boundary rows, long
+// rows, sub-block), added in a fixed order by whoever consumes them
 struct kmcf_part4 { const double *p[4]; int n[4]; };
 kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m);
 // tstate.hip: y[sub rows] += S x_sub (+ dot partials) on the compute stream; x_sub gathered from m->d_p
@@ -292,6 +293,9 @@ char *kmcf_p2p_window(kmcf_comm *c);
 bool kmcf_p2p_fits(kmcf_comm *c, size_t gather_bytes);
 int kmcf_p2p_check(kmcf_comm *c);          // KMCF_ERR_COMM if a bounded wait expired (call after a synchronisation)
 int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count);
+// finalize + all-reduce in ONE 1-block kernel: red[i] = sum over ranks of (sum of the partial arrays of part[i]);
+// returns at once (on every rank alike) when skip_if_done and S->done
+int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, kmcf_scalars *d_S, int skip_if_done);
 int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem);
 int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8);
 int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8);

@@ -112,6 +112,47 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_kernel(char *const *
     }
 }
 
+// The same with the block-level finalize in front: value i = sum of the partial arrays of part[i] (fixed order),
+// result into S->red[i].  One launch instead of a finalize kernel plus an exchange kernel per reduction.
+__global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_parts_kernel(char *const *__restrict__ peer, int P, int rank, kmcf_part4 p0, kmcf_part4 p1,
+                                                                         kmcf_part4 p2, int count, kmcf_scalars *__restrict__ S, int skip_if_done,
+                                                                         u64 seq, long long timeout, int *d_err, int *h_err)
+{
+    __shared__ double lds4[4];
+    __shared__ double mine[4];
+    if (skip_if_done && S->done) return;
+    const int t = threadIdx.x, parity = (int)(seq & 1);
+    for (int i = 0; i < count; ++i) {
+        const kmcf_part4 &r = i == 0 ? p0 : (i == 1 ? p1 : p2);
+        double v = 0.0;
+        for (int q = 0; q < 4; ++q)
+            for (int j = t; j < r.n[q]; j += KMCF_BLOCK) v += r.p[q][j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((t & 63) == 0) lds4[t >> 6] = v;
+        __syncthreads();
+        if (t == 0) mine[i] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+        __syncthreads();
+    }
+    if (t < P) {
+        double *slot = reinterpret_cast<double *>(peer[t] + P2P_OFF_RED_SLOT) + ((size_t)parity * P2P_MAXR + rank) * 4;
+        for (int i = 0; i < count; ++i)
+            __hip_atomic_store(reinterpret_cast<u64 *>(&slot[i]), (u64)__double_as_longlong(mine[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        store_release_system(reinterpret_cast<u64 *>(peer[t] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + rank, seq);
+    }
+    __syncthreads();
+    if (t < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + t, seq, timeout, d_err, h_err, 1);
+    __syncthreads();
+    if (t < count && __hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        const double *slots = reinterpret_cast<const double *>(peer[rank] + P2P_OFF_RED_SLOT) + (size_t)parity * P2P_MAXR * 4;
+        double s = 0.0;
+        for (int q = 0; q < P; ++q)
+            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&slots[(size_t)q * 4 + t]), __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_SYSTEM));
+        S->red[t] = s;
+    }
+}
+
 // pack + put: p[send_idx[i]] -> the neighbour's landing zone; the last block to finish raises the neighbours' flags
 __global__ __launch_bounds__(KMCF_BLOCK) void p2p_put_kernel(int n_send, const int *__restrict__ send_idx, const double *__restrict__ p,
                                                              double *const *__restrict__ put_ptr, int n_nb, u64 *const *__restrict__ put_flag,
@@ -330,6 +371,19 @@ int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count)
     KMCF_CHECK(count >= 1 && count <= 4, KMCF_ERR_ARG, "p2p all-reduce of %d doubles (1..4)", count);
     ++w->seq_red;
     p2p_allreduce_kernel<<<1, KMCF_BLOCK, 0, c->stream>>>(w->d_peer, c->nranks, c->rank, d_buf, count, w->seq_red, w->timeout_ticks, w->d_err, w->h_err);
+    KMCF_HIP(hipGetLastError());
+    return KMCF_OK;
+}
+
+int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, kmcf_scalars *d_S, int skip_if_done)
+{
+    kmcf_p2p *w = c->p2p;
+    KMCF_CHECK(count >= 1 && count <= 3, KMCF_ERR_ARG, "p2p all-reduce of %d partial sets (1..3)", count);
+    ++w->seq_red;
+    const kmcf_part4 none{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
+    p2p_allreduce_parts_kernel<<<1, KMCF_BLOCK, 0, c->stream>>>(w->d_peer, c->nranks, c->rank, part[0], count > 1 ? part[1] : none,
+                                                                count > 2 ? part[2] : none, count, d_S, skip_if_done, w->seq_red,
+                                                                w->timeout_ticks, w->d_err, w->h_err);
     KMCF_HIP(hipGetLastError());
     return KMCF_OK;
 }

@@ -41,12 +41,17 @@ def main():
     cal_p = p[2] * 1024 / (3 * vec)
     cal_xr = xr[2] * 1024 / (5 * vec)
     cal_w = xr[3] * 1024 / (2 * vec)
-    sp = max(get("spmv_"), key=lambda r: r[1])
-    corrected = 2.0 * sp[2] * 1024 + sp[3] * 1024
-    res = dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
+    # every SpMV kernel of the run (the bench line times the plan's kernel and, re-planned, the CSR stream kernel)
+    kernels = []
+    for sp in get("spmv_"):
+        if sp[1] < 3:
+            continue
+        corrected = 2.0 * sp[2] * 1024 + sp[3] * 1024
+        kernels.append(dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
+                            corrected_bytes_per_launch=int(corrected), rows=n_rows))
+    res = dict(kernels=kernels,
                calibration=dict(cg_p_fetch_ratio=round(cal_p, 4), cg_xr_fetch_ratio=round(cal_xr, 4),
-                                cg_xr_write_ratio=round(cal_w, 4)),
-               corrected_bytes_per_launch=int(corrected), rows=n_rows)
+                                cg_xr_write_ratio=round(cal_w, 4)))
     json.dump(res, open(out + ".json", "w"), indent=1)
     print(json.dumps(res))
 

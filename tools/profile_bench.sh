@@ -6,12 +6,12 @@
 # Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_DIR:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace + stats"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o b --output-format csv -- \
-    python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 30 > $OUT/bench_line.json 2> $OUT/stats.log
+    python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 > $OUT/bench_line.json 2> $OUT/stats.log
 tail -1 $OUT/bench_line.json
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c"

@@ -204,6 +204,22 @@ struct kmcf_matrix {
     bool dict_uploaded = false;
     int dict_n = 0;                    // dictionary entries in use
     int spmv_grid_coded = 0;           // interior grid while coded (its kernel's residency differs)
+    // Row-per-lane layout of the coded stream (spmv_sell_kernel, kmcf_spmv.hip): tiles of <= 256 rows sharing one
+    // x window; inside a tile the rows are sorted by length and dealt to the lanes of 4 waves; a wave's stream is
+    // [step q][lane][4 entries] padded to the wave's longest row.  Entry = LDS byte offset of value-times-x:
+    // ((code << sell_lw) | slot) << 3.  Derived from d_idx16's codes by sell_refresh_kernel whenever they change.
+    bool sell_ok = false;              // the layout exists (plan accepted it)
+    bool sell_dirty = true;            // codes in d_idx16 are newer than d_sell
+    bool sell_one = true;              // kernel variant: one register set for the stream (two: a tile ahead)
+    int sell_lw = 10, sell_nq = 0;     // log2 of the window slots per class; steps of 4 entries held in registers
+    int n_sell_tiles = 0, sell_grid = 0;
+    int64_t n_sell_wcols = 0, n_sell_entries = 0;
+    int4 *d_sell_tile = nullptr;       // (first row, rows, first window slot, window size) per tile
+    int2 *d_sell_wave = nullptr;       // per tile and wave: (first 8-byte group of its stream, steps)
+    int *d_sell_lrow = nullptr;        // per tile and lane: row - first row, -1 = idle lane
+    int *d_sell_wcol = nullptr;        // column of each window slot
+    unsigned short *d_sell = nullptr;  // the entry stream
+    int *d_sell_pos = nullptr;         // per row: position of its first entry in d_sell
     int spmv_u = 8;                    // stream: nnz per thread per chunk
     int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction
     int n_chunks = 0;
@@ -230,10 +246,13 @@ struct kmcf_kstate {
     double *d_gather = nullptr;
 };
 
+void kmcf_sell_free(kmcf_matrix *m);       // frees the row-per-lane layout (kmcf_spmv.hip)
+
 // grid of the interior SpMV pass = number of p.Ap partials it writes
 inline int kmcf_interior_grid(const kmcf_matrix *m)
 {
-    return (m->spmv_kind == 2 && m->coded) ? m->spmv_grid_coded : m->spmv_grid;
+    if (m->spmv_kind == 2 && m->coded) return (m->sell_ok && m->dict_n <= 3) ? m->sell_grid : m->spmv_grid_coded;
+    return m->spmv_grid;
 }
 
 // Sub-block operator of a split matrix A = A_csr + P^T S P (the T matrix's tunnel block): S acts on the

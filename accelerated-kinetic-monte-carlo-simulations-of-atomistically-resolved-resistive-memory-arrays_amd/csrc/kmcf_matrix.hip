@@ -404,6 +404,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         hipStreamSynchronize(m->comm->stream);
         hipStreamSynchronize(m->comm->comm_stream);
         kmcf_p2p_matrix_free(m);
+        kmcf_sell_free(m);
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,
@@ -427,9 +428,11 @@ extern "C" int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info)
     info->send_rows = m->n_send;
     info->boundary_rows = m->n_boundary_rows;
     info->spmv_kind = m->spmv_kind;
-    info->spmv_coded = (m->spmv_kind == 2 && m->coded) ? 1 : 0;
-    info->spmv_tiles = m->spmv_kind == 2 ? m->n_tiles : 0;
-    info->spmv_window_cols = m->spmv_kind == 2 ? m->n_wcols : 0;
+    const bool sell = m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3;
+    info->spmv_coded = (m->spmv_kind == 2 && m->coded) ? (sell ? 2 : 1) : 0;
+    info->spmv_tiles = m->spmv_kind == 2 ? (sell ? m->n_sell_tiles : m->n_tiles) : 0;
+    info->spmv_window_cols = m->spmv_kind == 2 ? (sell ? m->n_sell_wcols : m->n_wcols) : 0;
+    info->spmv_stream_entries = sell ? m->n_sell_entries : (info->spmv_coded ? (int64_t)m->h_row_ptr[m->n_short] : 0);
     return KMCF_OK;
 }
 

@@ -363,6 +363,178 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
     }
 }
 
+// ------------------------------------------------------------------ coded row-per-lane kernel
+// The coded window kernel above spends its time on instructions, not bytes (measured: ~213 VALU instructions per
+// wave and tile, two LDS lookups and a slot decode per entry, 4 lanes per row running to the longest of a wave's
+// 16 rows).  This layout removes the per-entry work instead of tuning it:
+//   * the value lookup moves out of the entry loop: the x window is staged ND times, once per dictionary value,
+//     already multiplied (xs[c][slot] = dict[c] * x[wcol[slot]]), and an entry IS the LDS byte offset of its
+//     product: ((code << LW) | slot) << 3.  Per entry: one 16-bit extract, one ds_read_b64, one add -- the
+//     same products, added in the row's column order;
+//   * one row per lane, rows of a tile (<= 256 rows, one shared window) sorted by length and dealt to the lanes, so
+//     a wave's lanes run equally long; the wave's stream is [step][lane][4 entries], padded to its longest row
+//     with the offset of a slot that holds 0.0.  A step is one coalesced 8-byte load per lane straight into
+//     registers: the stream never touches LDS, the trip count is a scalar, nothing in the loop is divergent;
+//   * a tile's whole stream (NQ steps) is requested one tile ahead, before that tile's x gathers, so that nothing
+//     the reduction waits for was issued behind a load of a later tile (waits are in issue order).
+// Stages per iteration k as in the kernel above: D(k) stage + reduce, C(k+1) gathers / row data / stream,
+// B(k+2) window map + lane rows, A(k+3) descriptors.
+typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries
+
+template <int NQ, int WQ>
+struct sell_regs {
+    sell_pair pk[NQ];                  // (unused when the kernel keeps one shared set)
+    double xr[WQ];
+    double xrow, dg;
+    int row, nq, wn;
+    bool valid;
+};
+
+template <int NQ, int LW, int ND, bool DOT, bool SKIP_BOUNDARY, bool ONESET>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
+    int n_tiles, const int4 *__restrict__ tile4, const int2 *__restrict__ swave, const int *__restrict__ lrow,
+    const int *__restrict__ wcol, const sell_pair *__restrict__ stream, const double *__restrict__ x, double *__restrict__ y,
+    const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S,
+    int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
+{
+    constexpr int W = 1 << LW, WQ = W / KMCF_BLOCK, BUF = ND * W;
+    typedef sell_regs<NQ, WQ> regs_t;
+    __shared__ double xs[2 * BUF];      // (exactly 32 KB for two values and 1024 slots: five blocks fill a CU's LDS)
+    if (check_done && S->done) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double dv[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) dv[c] = dict[c];
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Cx = (n_tiles + 7) >> 3;
+    const int gmax = min(Cx, n_tiles - xcd * Cx);
+    const int nt = gmax > bi ? (gmax - bi + nb8 - 1) / nb8 : 0;
+    double dot = 0.0;
+    if (nt > 0) {
+        const int c_first = xcd * Cx + bi;
+#define KMCF_TILE_OF(k) (c_first + min((k), nt - 1) * nb8)
+        // stage B: window map and lane rows of a tile
+        auto load_b = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) wc[q] = __builtin_nontemporal_load(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)));
+            lr = __builtin_nontemporal_load(lrow + (size_t)c * KMCF_BLOCK + tid);
+        };
+        // the same with (wave-scope, relaxed) atomic loads, which stay where they are written and cost nothing
+        // extra: the prologue must issue in the loop body's order (B before C) or the wait counts derived for the
+        // loop head are the prologue's, and the compiler sinks ordinary loads of __restrict__ data past anything
+        auto load_b_pinned = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) wc[q] = __hip_atomic_load(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            lr = __hip_atomic_load(lrow + (size_t)c * KMCF_BLOCK + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        };
+        // stage C: x gathers, row data, then the stream (issue order = the order they are waited for)
+        auto load_c = [&](const int4 &d, const int2 &sw, const int (&wc)[WQ], int lr, regs_t &t) {
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) t.xr[q] = x[wc[q]];
+            t.valid = lr >= 0;
+            t.row = d.x + (t.valid ? lr : 0);
+            t.xrow = x[t.row];
+            t.dg = diagv[t.row];
+            if (SKIP_BOUNDARY) t.valid = t.valid && is_boundary[t.row] == 0;
+            t.nq = sw.y;
+            t.wn = d.w;
+            if (!ONESET) {
+                const sell_pair *sp = stream + sw.x + lane;
+                const int last = max(sw.y - 1, 0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) t.pk[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);   // past the wave's end: re-read, a cache hit
+            }
+        };
+        sell_pair pk1[ONESET ? NQ : 1];      // ONESET: the one register set of the stream
+        int4 d1 = tile4[KMCF_TILE_OF(1)], d2 = tile4[KMCF_TILE_OF(2)];
+        int2 s1 = swave[KMCF_TILE_OF(1) * 4 + wv], s2 = swave[KMCF_TILE_OF(2) * 4 + wv];
+        int wca[WQ], wcb[WQ], lra, lrb;
+        regs_t ta, tb;
+        {   // prologue: window maps of tiles 0 and 1, then everything of tile 0 -- the issue order of the loop
+            // body (B before C), so that the wait counts the compiler derives for the loop head are the loop's own
+            const int4 d0 = tile4[c_first];
+            const int2 s0 = swave[c_first * 4 + wv];
+            load_b(c_first, d0, wca, lra);
+            load_b_pinned(KMCF_TILE_OF(1), d1, wcb, lrb);
+            __builtin_amdgcn_sched_barrier(0);
+            load_c(d0, s0, wca, lra, ta);
+            if (ONESET) {
+                const sell_pair *sp = stream + s0.x + lane;
+                const int last = max(s0.y - 1, 0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pk1[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);
+            }
+        }
+        // wu / lu: window map and lane rows of tile k+1 (loaded an iteration ago); wl / ll: receive tile k+2's.
+        // B is issued before C so that waiting for tile k+1's map next iteration leaves this iteration's stream
+        // loads in flight (waits are in issue order).
+        auto body = [&](int k, regs_t &cur, regs_t &nxt, double *xb, int (&wu)[WQ], int &lu, int (&wl)[WQ], int &ll) {
+            // ---- D(k), first half: products of the window into LDS (slots past the window: 0.0, the padding target)
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                const int slot = q * KMCF_BLOCK + tid;
+                const double v = slot < cur.wn ? cur.xr[q] : 0.0;
+#pragma unroll
+                for (int c = 0; c < ND; ++c) xb[c * W + slot] = dv[c] * v;
+            }
+            // ---- B(k+2), C(k+1), A(k+3)
+            load_b(KMCF_TILE_OF(k + 2), d2, wl, ll);
+            __builtin_amdgcn_sched_barrier(0);
+            load_c(d1, s1, wu, lu, nxt);
+            const sell_pair *spn = stream + s1.x + lane;     // ONESET: tile k+1's stream, requested step by step below
+            const int lastn = max(s1.y - 1, 0);
+            d1 = d2; s1 = s2;
+            d2 = tile4[KMCF_TILE_OF(k + 3)];
+            s2 = swave[KMCF_TILE_OF(k + 3) * 4 + wv];
+            __syncthreads();
+            // ---- D(k), second half: the lane's row
+            const char *base = reinterpret_cast<const char *>(xb);
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q < cur.nq) {
+                    const sell_pair e = ONESET ? pk1[q] : cur.pk[q];
+                    const double a0 = *reinterpret_cast<const double *>(base + (e.x & 0xffffu));
+                    const double a1 = *reinterpret_cast<const double *>(base + (e.x >> 16));
+                    const double a2 = *reinterpret_cast<const double *>(base + (e.y & 0xffffu));
+                    const double a3 = *reinterpret_cast<const double *>(base + (e.y >> 16));
+                    s += a0; s += a1; s += a2; s += a3;
+                }
+                // ONESET: the register a step has just freed receives the same step of the next tile
+                if (ONESET) pk1[q] = __builtin_nontemporal_load(spn + min(q, lastn) * 64);
+            }
+            // steps past the wave's end were loaded but never read: "use" the last one here, or the compiler finds
+            // their registers still pending at the loop head and drains every load before it reuses one
+            if (!ONESET) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(cur.pk[q]));
+            }
+            if (cur.valid) {
+                s += cur.dg * cur.xrow;
+                y[cur.row] = s;
+                if (DOT) dot += cur.xrow * s;
+            }
+        };
+        // Tiles in pairs (the two register sets swap roles), an odd last tile after the loop: with a conditional
+        // second half inside the loop the compiler sees a path from the first half back to the loop head and
+        // waits there for the stream it has just requested.
+        int k = 0;
+        for (; k + 1 < nt; k += 2) {
+            body(k, ta, tb, xs, wcb, lrb, wca, lra);
+            body(k + 1, tb, ta, xs + BUF, wca, lra, wcb, lrb);
+        }
+        if (k < nt) body(k, ta, tb, xs, wcb, lrb, wca, lra);
+#undef KMCF_TILE_OF
+    }
+    if (DOT) {
+        __syncthreads();                    // every wave is done with xs
+        double t = block_sum_256(dot, xs);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------ vector kernel
 template <int LPR, bool DOT, bool SKIP_BOUNDARY, bool ROW_LIST>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_kernel(
@@ -592,6 +764,97 @@ int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool 
     return pc;
 }
 
+#define KMCF_SELL_ARGS(isb, part) \
+    m->n_sell_tiles, m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, reinterpret_cast<const sell_pair *>(m->d_sell), \
+        m->d_p, m->d_Ap, isb, part, m->d_S, chk, m->d_dict, m->d_diagv
+
+template <int NQ, int LW, int ND, bool ONE>
+int sell_dispatch1(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+{
+    hipStream_t st = m->comm->stream;
+    const int chk = skip_if_done ? 1 : 0;
+    const bool skipb = (m->n_halo > 0);
+    const unsigned char *isb = skipb ? m->d_is_boundary : nullptr;
+    double *part = with_dot ? m->d_part_a : nullptr;
+    const int grid = launch ? m->sell_grid : 0;
+    int pc = 0;
+    if (with_dot) {
+        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, true, true, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        else run_or_query(spmv_sell_kernel<NQ, LW, ND, true, false, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+    } else {
+        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, false, true, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        else run_or_query(spmv_sell_kernel<NQ, LW, ND, false, false, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+    }
+    return pc;
+}
+
+template <int NQ, int LW, int ND>
+int sell_dispatch(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+{
+    return m->sell_one ? sell_dispatch1<NQ, LW, ND, true>(m, launch, with_dot, skip_if_done)
+               : sell_dispatch1<NQ, LW, ND, false>(m, launch, with_dot, skip_if_done);
+}
+
+// instantiated (steps, log2 window, dictionary size) triples; dictionaries of one value run as two (second = 0)
+constexpr int KMCF_SELL_NQ[] = {8, 13, 16};
+
+template <int LW>
+int sell_dispatch_lw(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+{
+    const int nd = m->dict_n <= 2 ? 2 : 3;
+    switch (m->sell_nq * 10 + nd) {
+        case 82: return sell_dispatch<8, LW, 2>(m, launch, with_dot, skip_if_done);
+        case 83: return sell_dispatch<8, LW, 3>(m, launch, with_dot, skip_if_done);
+        case 132: return sell_dispatch<13, LW, 2>(m, launch, with_dot, skip_if_done);
+        case 133: return sell_dispatch<13, LW, 3>(m, launch, with_dot, skip_if_done);
+        case 162: return sell_dispatch<16, LW, 2>(m, launch, with_dot, skip_if_done);
+        default: return sell_dispatch<16, LW, 3>(m, launch, with_dot, skip_if_done);
+    }
+}
+
+int sell_dispatch_any(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+{
+    if (m->sell_lw == 9) return sell_dispatch_lw<9>(m, launch, with_dot, skip_if_done);
+    return sell_dispatch_lw<10>(m, launch, with_dot, skip_if_done);
+}
+
+inline bool sell_active(const kmcf_matrix *m) { return m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3; }
+
+// The stream's value codes follow d_idx16's (which the assembly kernels write): one pass whenever they changed.
+template <int LPR>
+__global__ __launch_bounds__(KMCF_BLOCK) void sell_refresh_kernel(int n, const int *__restrict__ row_ptr,
+                                                                  const int *__restrict__ diag_pos,
+                                                                  const unsigned short *__restrict__ idx16,
+                                                                  const int *__restrict__ sell_pos,
+                                                                  unsigned short *__restrict__ sell, int lw)
+{
+    constexpr int RPB = KMCF_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    const unsigned int slot_part = (unsigned int)(((1 << lw) - 1) << 3);
+    for (int r = blockIdx.x * RPB + threadIdx.x / LPR; r < n; r += gridDim.x * RPB) {
+        const int b = row_ptr[r], e = row_ptr[r + 1], dp = diag_pos[r];
+        const int len = e - b - (dp >= 0 ? 1 : 0);
+        const int pos0 = sell_pos[r];
+        for (int k = lane; k < len; k += LPR) {
+            const int j = b + k + ((dp >= 0 && b + k >= dp) ? 1 : 0);
+            const unsigned int code = (unsigned int)idx16[j] >> KMCF_SLOT_BITS;
+            const int pos = pos0 + (k >> 2) * 256 + (k & 3);
+            sell[pos] = (unsigned short)((sell[pos] & slot_part) | (code << (lw + 3)));
+        }
+    }
+}
+
+int sell_refresh(kmcf_matrix *m)
+{
+    if (!m->sell_dirty) return KMCF_OK;
+    constexpr int LPR = 4;
+    sell_refresh_kernel<LPR><<<grid_for(m->n_short, KMCF_BLOCK / LPR), KMCF_BLOCK, 0, m->comm->stream>>>(
+        m->n_short, m->d_row_ptr, m->d_diag_pos, m->d_idx16, m->d_sell_pos, m->d_sell, m->sell_lw);
+    KMCF_HIP(hipGetLastError());
+    m->sell_dirty = false;
+    return KMCF_OK;
+}
+
 int window_dispatch_any(kmcf_matrix *m, int which, bool launch, bool with_dot, bool skip_if_done)
 {
     switch (m->spmv_u * 100 + m->spmv_wmax / KMCF_BLOCK) {
@@ -619,9 +882,23 @@ int window_grid(kmcf_matrix *m, int which)
     return g;
 }
 
+int sell_grid(kmcf_matrix *m)
+{
+    int cus = 0;
+    const int per_cu = sell_dispatch_any(m, false, true, false);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->comm->device) != hipSuccess) cus = 0;
+    const int resident = per_cu * cus;
+    int g = grid_for(m->n_sell_tiles, 1);
+    if (resident >= 8 && g > resident) g = resident / 8 * 8;
+    return g;
+}
+
 void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
-    if (m->spmv_kind == 2) {
+    if (sell_active(m)) {
+        if (sell_refresh(m) != KMCF_OK) return;
+        sell_dispatch_any(m, true, with_dot, skip_if_done);
+    } else if (m->spmv_kind == 2) {
         window_dispatch_any(m, m->coded ? 1 : 0, true, with_dot, skip_if_done);
     } else if (m->spmv_kind == 1) {
         const int key = m->spmv_u * 100 + m->spmv_lpr2;
@@ -650,6 +927,8 @@ int env_int(const char *name, int dflt)
 // a tile or, with `judge`, if a window column is used by fewer than two entries on average: columns too
 // scattered for a window to pay off, the stream kernel's direct gathers serve those better (K: ~5 entries
 // per window column).
+int plan_sell(kmcf_matrix *m, const std::vector<int> &col);
+
 int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 {
     *ok = false;
@@ -738,6 +1017,124 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_code_fail), sizeof(int)));
     m->coded = false;
     *ok = true;
+    if (for_coded) KMCF_TRY(plan_sell(m, col));
+    return KMCF_OK;
+}
+
+// Row-per-lane layout for the coded kernel (spmv_sell_kernel).  Declines (sell_ok stays false, the coded window
+// kernel runs) when a row holds more off-diagonal entries than the largest instantiated register file (4 x 16)
+// or when padding would add more than half to the stream.
+int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
+{
+    m->sell_ok = false;
+    if (env_int("KMCF_SPMV_SELL", 1) == 0) return KMCF_OK;
+    const int n = m->n_short;
+    const std::vector<int> &rp = m->h_row_ptr;
+    const std::vector<int> &dpos = m->h_diag_pos;
+    int lw = env_int("KMCF_SPMV_SELL_LW", 10);
+    if (lw != 9 && lw != 10) lw = 10;
+    const int W = 1 << lw, wcap = W - 1;             // slot W - 1 stays empty: the padding entries' target
+    int maxlen = 0;
+    for (int i = 0; i < n; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i] - (dpos[i] >= 0 ? 1 : 0));
+    int nq = 0;
+    for (int v : KMCF_SELL_NQ)
+        if (4 * v >= maxlen) { nq = v; break; }
+    if (nq == 0) return KMCF_OK;
+    // rows per tile: 256 where that still leaves every CU several tiles, fewer on small matrices
+    int row_cap = KMCF_BLOCK;
+    while (row_cap > 64 && n / row_cap < 2048) row_cap /= 2;
+    row_cap = std::min(KMCF_BLOCK, std::max(64, env_int("KMCF_SPMV_SELL_ROWS", row_cap) / 64 * 64));
+    const unsigned short pad = (unsigned short)((W - 1) << 3);
+    std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1), uniq, wcol, ord, pos((size_t)n, 0);
+    std::vector<int4> tiles;
+    std::vector<int2> waves;
+    std::vector<int> lrow;
+    std::vector<unsigned short> st;
+    int64_t real = 0;
+    auto len_of = [&](int i) { return rp[i + 1] - rp[i] - (dpos[i] >= 0 ? 1 : 0); };
+    int r = 0;
+    while (r < n) {
+        uniq.clear();
+        int e = r;
+        while (e < n && e - r < row_cap) {
+            const size_t before = uniq.size();
+            for (int j = rp[e]; j < rp[e + 1]; ++j)
+                if (j != dpos[e] && slot[col[j]] < 0) { slot[col[j]] = 0; uniq.push_back(col[j]); }
+            if ((int)uniq.size() > wcap) {
+                for (size_t q = before; q < uniq.size(); ++q) slot[uniq[q]] = -1;
+                uniq.resize(before);
+                break;
+            }
+            ++e;
+        }
+        if (e == r) return KMCF_OK;                  // (cannot happen: a row holds <= 64 entries)
+        std::sort(uniq.begin(), uniq.end());
+        for (size_t q = 0; q < uniq.size(); ++q) slot[uniq[q]] = (int)q;
+        const int nr = e - r;
+        ord.resize((size_t)nr);
+        for (int i = 0; i < nr; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len_of(r + a) > len_of(r + b); });
+        tiles.push_back(make_int4(r, nr, (int)wcol.size(), (int)uniq.size()));
+        for (int t = 0; t < KMCF_BLOCK; ++t) lrow.push_back(t < nr ? ord[t] : -1);
+        for (int w = 0; w < KMCF_BLOCK / 64; ++w) {
+            const int t0 = 64 * w;
+            const int wq = t0 < nr ? (len_of(r + ord[t0]) + 3) / 4 : 0;     // sorted: the wave's first lane is its longest
+            const size_t base = st.size() / 4;                              // in 8-byte groups
+            waves.push_back(make_int2((int)base, wq));
+            st.resize(st.size() + (size_t)wq * 256, pad);
+            for (int t = t0; t < std::min(t0 + 64, nr); ++t) {
+                const int row = r + ord[t];
+                pos[row] = (int)((base + (t - t0)) * 4);
+                int k = 0;
+                for (int j = rp[row]; j < rp[row + 1]; ++j) {
+                    if (j == dpos[row]) continue;
+                    st[(size_t)pos[row] + (size_t)(k >> 2) * 256 + (k & 3)] = (unsigned short)(slot[col[j]] << 3);
+                    ++k;
+                }
+                real += k;
+            }
+        }
+        for (int cj : uniq) slot[cj] = -1;
+        wcol.insert(wcol.end(), uniq.begin(), uniq.end());
+        r = e;
+    }
+    if (st.size() / 4 > (size_t)0x7fffff00 || (double)st.size() > 1.5 * (double)real + 4096.0 * tiles.size()) return KMCF_OK;
+    const int nt = (int)tiles.size();
+    if (getenv("KMCF_SPMV_VERBOSE"))
+        fprintf(stderr, "kmcf row-per-lane plan: %d tiles of <= %d rows, %.1f rows, %.1f window columns per tile, %lld entries + %.1f %% padding, %d steps\n",
+                nt, row_cap, double(n) / nt, double(wcol.size()) / nt, (long long)real, 100.0 * (double(st.size()) / double(std::max<int64_t>(real, 1)) - 1.0), nq);
+    if (getenv("KMCF_SPMV_VERBOSE")) {
+        std::vector<long long> hist(20, 0), rows(20, 0);
+        for (const int2 &w : waves) ++hist[std::min(w.y, 19)];
+        for (int i = 0; i < n; ++i) ++rows[std::min((len_of(i) + 3) / 4, 19)];
+        fprintf(stderr, "  steps: waves / rows ");
+        for (int q = 0; q < 20; ++q)
+            if (hist[q] || rows[q]) fprintf(stderr, " %d: %lld / %lld;", q, hist[q], rows[q]);
+        fprintf(stderr, "\n");
+    }
+    m->n_sell_entries = (int64_t)st.size();
+    m->n_sell_wcols = (int64_t)wcol.size();
+    st.resize(st.size() + 128 * 4, pad);              // idle waves read one group per lane at their (empty) stream's start
+    wcol.push_back(0);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell_tile), tiles.size() * sizeof(int4)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell_wave), waves.size() * sizeof(int2)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell_lrow), lrow.size() * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell_wcol), wcol.size() * sizeof(int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell), st.size() * sizeof(unsigned short)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sell_pos), (size_t)n * sizeof(int)));
+    KMCF_HIP(hipMemcpy(m->d_sell_tile, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_sell_wave, waves.data(), waves.size() * sizeof(int2), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_sell_lrow, lrow.data(), lrow.size() * sizeof(int), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_sell_wcol, wcol.data(), wcol.size() * sizeof(int), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_sell, st.data(), st.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(m->d_sell_pos, pos.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    m->n_sell_tiles = nt;
+    m->sell_lw = lw;
+    m->sell_nq = nq;
+    m->sell_dirty = true;
+    m->sell_one = env_int("KMCF_SPMV_SELL_ONE", 1) != 0;
+    m->sell_ok = true;
+    m->sell_grid = 0;                                 // with the dictionary (its size selects the instance)
     return KMCF_OK;
 }
 
@@ -862,7 +1259,13 @@ int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
         m->dict_uploaded = true;
     }
     if (m->spmv_grid_coded <= 0) m->spmv_grid_coded = window_grid(m, 1);
+    if (m->sell_ok && (m->sell_grid <= 0 || (m->dict_n <= 2) != (nd <= 2))) {
+        m->dict_n = nd;
+        m->sell_grid = sell_grid(m);
+        if (getenv("KMCF_SPMV_VERBOSE")) fprintf(stderr, "kmcf row-per-lane kernel: grid %d for %d tiles\n", m->sell_grid, m->n_sell_tiles);
+    }
     m->dict_n = nd;
+    m->sell_dirty = true;                               // the caller is about to write (or has just written) the codes
     m->coded = true;
     return KMCF_OK;
 }
@@ -1042,6 +1445,17 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
 }
 
 // Re-plan the SpMV of an existing matrix from the KMCF_SPMV_* environment (tuning aid).
+void kmcf_sell_free(kmcf_matrix *m)
+{
+    void *ptrs[] = {m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, m->d_sell, m->d_sell_pos};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    m->d_sell_tile = nullptr; m->d_sell_wave = nullptr; m->d_sell_lrow = nullptr;
+    m->d_sell_wcol = nullptr; m->d_sell = nullptr; m->d_sell_pos = nullptr;
+    m->sell_ok = false;
+    m->n_sell_tiles = 0;
+}
+
 extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
 {
     KMCF_CHECK(m && m->d_val, KMCF_ERR_ARG, "kmcf_spmv_replan: bad matrix");
@@ -1057,6 +1471,7 @@ extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
     if (m->d_diagv) { hipFree(m->d_diagv); m->d_diagv = nullptr; }
     if (m->d_diag_pos) { hipFree(m->d_diag_pos); m->d_diag_pos = nullptr; }
     if (m->d_code_fail) { hipFree(m->d_code_fail); m->d_code_fail = nullptr; }
+    kmcf_sell_free(m);
     m->n_tiles = 0;
     m->coded = false;
     m->dict_uploaded = false;

@@ -21,7 +21,7 @@ class MatrixInfo(C.Structure):
     _fields_ = [("matrix_size", C.c_int), ("rows_this_rank", C.c_int), ("nnz", C.c_int64),
                 ("number_of_neighbours", C.c_int), ("halo_cols", C.c_int), ("send_rows", C.c_int),
                 ("boundary_rows", C.c_int), ("spmv_kind", C.c_int), ("spmv_coded", C.c_int), ("spmv_tiles", C.c_int),
-                ("spmv_window_cols", C.c_int64)]
+                ("spmv_window_cols", C.c_int64), ("spmv_stream_entries", C.c_int64)]
 
 
 class TStateInfo(C.Structure):

@@ -157,10 +157,16 @@ def main():
     # Algorithmic bytes of one launch = what the kernel's matrix format makes it read and write once
     # (DESIGN.md 3.1): CSR 12 B/nnz + 20 B/row; window format 10 B/nnz (f64 value + 16-bit
     # slot) + 4 B per window column + 20 B/row; dictionary-coded window format 2 B/nnz + 4 B per window column
-    # + 28 B/row (row_ptr, diagonal, x, y).  csr_equivalent prices the same launch at the CSR figure.
+    # + 28 B/row (row_ptr, diagonal, x, y); row-per-lane coded format below.  csr_equivalent prices the same launch at the CSR figure.
     minfo = mat.info()
     csr_bytes = 12.0 * nnz_loc + 20.0 * n_loc
-    if minfo["spmv_kind"] == 2 and minfo["spmv_coded"]:
+    if minfo["spmv_kind"] == 2 and minfo["spmv_coded"] == 2:
+        # row-per-lane coded format: 2 B per streamed entry (off-diagonals + padding to the wave's longest row) +
+        # 4 B per window column + 28 B/row (lane row, diagonal, x, y) + 48 B of descriptors per tile
+        kname = "spmv_sell_kernel (row-per-lane window SpMV, dictionary-coded values, fused p.Ap)"
+        alg_bytes = (2.0 * minfo["spmv_stream_entries"] + 4.0 * minfo["spmv_window_cols"] + 28.0 * n_loc
+                     + 48.0 * minfo["spmv_tiles"])
+    elif minfo["spmv_kind"] == 2 and minfo["spmv_coded"]:
         kname = "spmv_wcode_kernel (window SpMV, dictionary-coded values, fused p.Ap)"
         alg_bytes = 2.0 * nnz_loc + 4.0 * minfo["spmv_window_cols"] + 28.0 * n_loc
     elif minfo["spmv_kind"] == 2:

@@ -129,9 +129,10 @@ typedef struct {
     int send_rows;            /* sum over k>=1 of nnz_rows_per_neighbour[k]         */
     int boundary_rows;        /* local rows that reference a halo column            */
     int spmv_kind;            /* 0 vec, 1 stream, 2 window (LDS-staged x window)    */
-    int spmv_coded;           /* 1: values currently dictionary-coded (2 B/nnz)     */
-    int spmv_tiles;           /* window kernel: number of tiles                     */
-    int64_t spmv_window_cols; /* window kernel: sum of the tiles' window sizes      */
+    int spmv_coded;           /* values currently dictionary-coded (2 B/nnz): 1 window kernel, 2 row-per-lane kernel */
+    int spmv_tiles;           /* window / row-per-lane kernel: number of tiles      */
+    int64_t spmv_window_cols; /* the same: sum of the tiles' window sizes           */
+    int64_t spmv_stream_entries; /* coded kernels: 16-bit entries streamed per launch (row-per-lane: padding included) */
 } kmcf_matrix_info_t;
 int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info);
 

@@ -56,7 +56,7 @@ def test_full_size_plan_and_row_sums(full, km):
     S, d, buf, mat, n = full["S"], full["d"], full["buf"], full["mat"], full["n"]
     info = mat.info()
     assert info["rows_this_rank"] == n == 1597080 and info["nnz"] == 41834706
-    assert info["spmv_kind"] == 2 and info["spmv_coded"] == CODED_ON
+    assert info["spmv_kind"] == 2 and (info["spmv_coded"] > 0) == bool(CODED_ON)
     v = S.k_vectors(buf)
     rp, col = S.k_pattern(buf, 0)
     # off-diagonals are one of the two conductances, the diagonal is positive
@@ -93,7 +93,7 @@ def test_full_size_spmv_symmetry_linearity_and_kernels(full, km, monkeypatch):
     finally:
         monkeypatch.delenv("KMCF_SPMV_KIND", raising=False)
         km.lib.check(lib.kmcf_spmv_replan(mat.handle), "replan")
-        assert mat.info()["spmv_kind"] == 2 and mat.info()["spmv_coded"] == CODED_ON
+        assert mat.info()["spmv_kind"] == 2 and (mat.info()["spmv_coded"] > 0) == bool(CODED_ON)
 
 
 def test_full_size_solve_properties(full):
@@ -181,7 +181,7 @@ def test_full_size_current_and_heat(full, km):
     assert dens >= 0.4, dens
     mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
     minfo = mat.info()
-    assert minfo["spmv_kind"] == 2 and minfo["spmv_coded"] == CODED_ON     # long rows did not displace the window kernel
+    assert minfo["spmv_kind"] == 2 and m(info["spmv_coded"] > 0) == bool(CODED_ON)     # long rows did not displace the window kernel
 
     def tspmv(x):
         p = t.as_tensor(np.ascontiguousarray(x), device="cuda")

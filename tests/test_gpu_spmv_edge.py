@@ -59,7 +59,7 @@ def test_tiny_matrices(km, torch, monkeypatch, name, kind):
     info = mat.info()
     assert info["spmv_kind"] == kind, info
     if kind == 2:
-        assert info["spmv_coded"] == CODED_ON     # few distinct off-diagonal values in every case
+        assert (info["spmv_coded"] > 0) == bool(CODED_ON)     # few distinct off-diagonal values in every case
     x = np.linspace(1.0, 2.0, n)
     p = torch.as_tensor(x, device="cuda")
     Ap = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
@@ -88,7 +88,10 @@ def test_dictionary_size_limit(km, torch, monkeypatch, ndistinct, coded):
     comm.connect()
     mat = S.Distributed_matrix(comm, n, [n], [0], M.indices, M.indptr, M.data)
     info = mat.info()
-    assert info["spmv_kind"] == 2 and info["spmv_coded"] == (coded & CODED_ON), info
+    # (one value: row-per-lane kernel, 2; 62 values: coded window kernel, 1; 63: values streamed)
+    assert info["spmv_kind"] == 2 and (info["spmv_coded"] > 0) == bool(coded & CODED_ON), info
+    if CODED_ON and coded and os.environ.get("KMCF_SPMV_SELL", "1") != "0":
+        assert info["spmv_coded"] == (2 if ndistinct <= 3 else 1), info
     x = rng.standard_normal(n)
     p = torch.as_tensor(x, device="cuda")
     Ap = torch.empty_like(p)

@@ -12,6 +12,9 @@ import numpy as np
 import pytest
 
 CODED_ON = int(os.environ.get("KMCF_SPMV_CODED", "1") != "0")   # the suite is green under KMCF_SPMV_CODED=0 too
+SELL_ON = int(os.environ.get("KMCF_SPMV_SELL", "1") != "0")      # ... and under KMCF_SPMV_SELL=0
+# info["spmv_coded"]: 0 values streamed, 1 coded window kernel, 2 coded row-per-lane kernel (<= 3 values, rows <= 64)
+CODED_K = (2 if SELL_ON else 1) * CODED_ON
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +27,7 @@ def torch():
 
 
 def _replan(km, mat, monkeypatch, **env):
-    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED"):
+    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED", "SELL", "SELL_ROWS", "SELL_LW"):
         monkeypatch.delenv("KMCF_SPMV_" + k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv("KMCF_SPMV_" + k, str(v))
@@ -51,7 +54,7 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
     info = mat.info()
     # default plan of the (brick-ordered) K matrix: window kernel, values coded by the assembly
-    assert info["spmv_kind"] == 2 and info["spmv_coded"] == CODED_ON
+    assert info["spmv_kind"] == 2 and info["spmv_coded"] == CODED_K
     assert info["spmv_tiles"] > 0 and 0 < info["spmv_window_cols"] < info["nnz"]
     rng = np.random.default_rng(3)
     x = rng.standard_normal(ks.n)
@@ -70,15 +73,22 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     assert np.abs(mat.get_values() - A["val"]).max() <= 1e-12 * np.abs(A["val"]).max()
     res = {}
     for name, env in (("window_plain", dict(KIND=2, CODED=0)), ("stream", dict(KIND=1)), ("vec", dict(KIND=0)),
-                      ("window_u4", dict(KIND=2, U=4, WQ=2)), ("window_wq4", dict(KIND=2, WQ=4, CODED=0))):
+                      ("window_coded", dict(KIND=2, SELL=0)), ("window_u4", dict(KIND=2, U=4, WQ=2, SELL=0)),
+                      ("window_wq4", dict(KIND=2, WQ=4, CODED=0)), ("lane_rows128", dict(KIND=2, SELL=1, SELL_ROWS=128)),
+                      ("lane_lw9", dict(KIND=2, SELL=1, SELL_LW=9))):
         inf = _replan(km, mat, monkeypatch, **env)
         assert inf["spmv_kind"] == env["KIND"], (name, inf)
-        assert inf["spmv_coded"] == (1 if env["KIND"] == 2 and env.get("CODED", 1) else 0), (name, inf)
+        want_coded = 0 if env["KIND"] != 2 or not env.get("CODED", 1) else (2 if env.get("SELL", 1) else 1)
+        assert inf["spmv_coded"] == want_coded, (name, inf)
         res[name] = run()
         assert np.all(np.abs(res[name] - want) <= 1e-13 * bound), name
     np.testing.assert_array_equal(res["window_plain"], res["stream"])        # same products, same order
     np.testing.assert_array_equal(res["window_plain"], res["window_wq4"])
-    assert np.all(np.abs(res["window_u4"] - y_coded) <= 1e-15 * bound + 1e-300)   # both coded: diagonal last
+    assert np.all(np.abs(res["window_u4"] - res["window_coded"]) <= 1e-15 * bound + 1e-300)   # both coded: diagonal last
+    # the row-per-lane kernel adds a row's products in column order, whatever its tiling
+    np.testing.assert_array_equal(res["lane_rows128"], y_coded)
+    np.testing.assert_array_equal(res["lane_lw9"], y_coded)
+    assert np.all(np.abs(res["window_coded"] - y_coded) <= 4e-16 * 53 * bound)
     assert np.all(np.abs(res["window_plain"] - y_coded) <= 4e-16 * 53 * bound)
 
     # the solve itself, coded against plain values: same system, rounding-level different iterates
@@ -86,7 +96,7 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     for name, env in (("coded", dict()), ("plain", dict(CODED=0))):
         _replan(km, mat, monkeypatch, **env)
         S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])
-        assert mat.info()["spmv_coded"] == (1 if name == "coded" else 0)
+        assert mat.info()["spmv_coded"] == (CODED_K if name == "coded" else 0)
         buf.site_potential_boundary.zero_()        # the solve starts from the previous potential (warm start)
         st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                                d["nn_dist"], len(d["metals"]), 0)
@@ -138,7 +148,7 @@ def test_generic_matrix_value_coding(km, torch):
     Ap = torch.empty_like(p)
     mat = S.Distributed_matrix(comm, n, [n], [0], M3.indices, M3.indptr, M3.data)
     info = mat.info()
-    assert info["spmv_kind"] == 2 and info["spmv_coded"] == CODED_ON, info
+    assert info["spmv_kind"] == 2 and info["spmv_coded"] == CODED_K, info
     mat.spmv(p, Ap)
     np.testing.assert_allclose(Ap.cpu().numpy(), M3 @ x, rtol=1e-13, atol=1e-13 * np.abs(M3 @ x).max())
     np.testing.assert_array_equal(mat.get_values(), M3.data)
@@ -153,7 +163,7 @@ def test_generic_matrix_value_coding(km, torch):
     v = M3.data.copy()
     v[v == -0.25] = -0.0
     mat.set_values(v)
-    assert mat.info()["spmv_coded"] == CODED_ON
+    assert mat.info()["spmv_coded"] == CODED_K
     mat.spmv(p, Ap)
     Mz = M3.copy()
     Mz.data = v

@@ -210,7 +210,8 @@ struct kmcf_matrix {
     // ((code << sell_lw) | slot) << 3.  Derived from d_idx16's codes by sell_refresh_kernel whenever they change.
     bool sell_ok = false;              // the layout exists (plan accepted it)
     bool sell_dirty = true;            // codes in d_idx16 are newer than d_sell
-    bool sell_one = true;              // kernel variant: one register set for the stream (two: a tile ahead)
+    std::vector<int> h_sell_cuts;      // end row of every tile, fixed by kmcf_sell_refine_order (empty: plan_sell cuts greedily)
+    bool sell_ident = false;           // every tile's rows are already sorted by length: lane t owns row r0 + t
     int sell_lw = 10, sell_nq = 0;     // log2 of the window slots per class; steps of 4 entries held in registers
     int n_sell_tiles = 0, sell_grid = 0;
     int64_t n_sell_wcols = 0, n_sell_entries = 0;
@@ -247,6 +248,7 @@ struct kmcf_kstate {
 };
 
 void kmcf_sell_free(kmcf_matrix *m);       // frees the row-per-lane layout (kmcf_spmv.hip)
+void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *col, std::vector<int> &perm, std::vector<int> &cuts);
 
 // grid of the interior SpMV pass = number of p.Ap partials it writes
 inline int kmcf_interior_grid(const kmcf_matrix *m)

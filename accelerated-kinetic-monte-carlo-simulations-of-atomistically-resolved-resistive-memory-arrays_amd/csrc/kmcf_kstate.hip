@@ -417,9 +417,11 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
     if (rc != KMCF_OK) { delete k; return rc; }
     // position of the diagonal entry (insert_into_diag searches it every call, :795-814), in the
     // internal CSR: entries keep their order inside a row
+    // (the matrix may have refined the order it was given: its own h_perm is the one in force)
+    const std::vector<int> &perm_m = k->K->h_perm;
     std::vector<int> diag_pos((size_t)n_loc, -1);
     for (int i = 0; i < n_loc; ++i) {
-        const int r = perm.empty() ? i : perm[i];
+        const int r = perm_m.empty() ? i : perm_m[i];
         for (int j = k->h_row_ptr[r]; j < k->h_row_ptr[r + 1]; ++j)
             if (k->h_col[j] == disp + r) { diag_pos[i] = k->K->h_row_ptr[i] + (j - k->h_row_ptr[r]); break; }
     }

@@ -193,6 +193,20 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         std::stable_partition(perm_eff.begin(), perm_eff.end(), [&](int r) { return rp[r + 1] - rp[r] <= long_thr; });
     }
     m->n_short = n_loc - n_long;
+    // rows of a row-per-lane tile sorted by length (kmcf_spmv.hip: lane t of a tile owns row r0 + t)
+    if (m->n_short >= 2) {
+        if (perm_eff.empty()) { perm_eff.resize((size_t)n_loc); for (int i = 0; i < n_loc; ++i) perm_eff[i] = i; }
+        bool valid = true;
+        {
+            std::vector<unsigned char> seen((size_t)n_loc, 0);
+            for (int i = 0; i < n_loc && valid; ++i) {
+                const int r = perm_eff[i];
+                valid = r >= 0 && r < n_loc && !seen[r];
+                if (valid) seen[r] = 1;
+            }
+        }
+        if (valid) kmcf_sell_refine_order(m->n_short, n_loc + m->n_halo, rp.data(), col_local.data(), perm_eff, m->h_sell_cuts);
+    }
     if (!perm_eff.empty()) {
         const int *hp = perm_eff.data();
         std::vector<int> inv((size_t)n_loc, -1);

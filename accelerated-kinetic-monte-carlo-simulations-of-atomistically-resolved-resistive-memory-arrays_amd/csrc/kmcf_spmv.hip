@@ -371,26 +371,28 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 //     already multiplied (xs[c][slot] = dict[c] * x[wcol[slot]]), and an entry IS the LDS byte offset of its
 //     product: ((code << LW) | slot) << 3.  Per entry: one 16-bit extract, one ds_read_b64, one add -- the
 //     same products, added in the row's column order;
-//   * one row per lane, rows of a tile (<= 256 rows, one shared window) sorted by length and dealt to the lanes, so
-//     a wave's lanes run equally long; the wave's stream is [step][lane][4 entries], padded to its longest row
-//     with the offset of a slot that holds 0.0.  A step is one coalesced 8-byte load per lane straight into
-//     registers: the stream never touches LDS, the trip count is a scalar, nothing in the loop is divergent;
-//   * a tile's whole stream (NQ steps) is requested one tile ahead, before that tile's x gathers, so that nothing
-//     the reduction waits for was issued behind a load of a later tile (waits are in issue order).
-// Stages per iteration k as in the kernel above: D(k) stage + reduce, C(k+1) gathers / row data / stream,
-// B(k+2) window map + lane rows, A(k+3) descriptors.
+//   * one row per lane, rows of a tile (<= 256 rows, one shared window) sorted by length, so a wave's lanes run
+//     equally long; the wave's stream is [step][lane][4 entries], padded to its longest row with the offset of
+//     a slot that holds 0.0.  A step is one coalesced 8-byte load per lane straight into registers: the stream
+//     never touches LDS, the trip count is a scalar, nothing in the loop is divergent.  The sort is part of the
+//     matrix's internal row order (kmcf_sell_refine_order), so lane t of a tile owns row r0 + t and x, the
+//     diagonal and y are contiguous (IDENT); a matrix ordered otherwise reads its lane rows from lrow;
+//   * the register a step frees receives the same step of the next tile at once: one register set holds the
+//     stream of two tiles in flight (with a second set: 106 VGPRs, 4 blocks per CU, 41.9 us; with one: 81,
+//     5 blocks, 37.6 us on the 40 nm K matrix).
+// Stages per iteration k as in the kernel above: D(k) stage + reduce (+ stream of k+1), C(k+1) gathers and row
+// data, B(k+2) window map (+ lane rows), A(k+3) descriptors.
 typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries
 
-template <int NQ, int WQ>
+template <int WQ>
 struct sell_regs {
-    sell_pair pk[NQ];                  // (unused when the kernel keeps one shared set)
     double xr[WQ];
     double xrow, dg;
     int row, nq, wn;
     bool valid;
 };
 
-template <int NQ, int LW, int ND, bool DOT, bool SKIP_BOUNDARY, bool ONESET>
+template <int NQ, int LW, int ND, bool DOT, bool SKIP_BOUNDARY, bool IDENT>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     int n_tiles, const int4 *__restrict__ tile4, const int2 *__restrict__ swave, const int *__restrict__ lrow,
     const int *__restrict__ wcol, const sell_pair *__restrict__ stream, const double *__restrict__ x, double *__restrict__ y,
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
 {
     constexpr int W = 1 << LW, WQ = W / KMCF_BLOCK, BUF = ND * W;
-    typedef sell_regs<NQ, WQ> regs_t;
+    typedef sell_regs<WQ> regs_t;
     __shared__ double xs[2 * BUF];      // (exactly 32 KB for two values and 1024 slots: five blocks fill a CU's LDS)
     if (check_done && S->done) return;
     const int tid = threadIdx.x;
@@ -415,11 +417,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     if (nt > 0) {
         const int c_first = xcd * Cx + bi;
 #define KMCF_TILE_OF(k) (c_first + min((k), nt - 1) * nb8)
-        // stage B: window map and lane rows of a tile
+        // stage B: window map (and lane rows) of a tile
         auto load_b = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
 #pragma unroll
             for (int q = 0; q < WQ; ++q) wc[q] = __builtin_nontemporal_load(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)));
-            lr = __builtin_nontemporal_load(lrow + (size_t)c * KMCF_BLOCK + tid);
+            if (!IDENT) lr = __builtin_nontemporal_load(lrow + (size_t)c * KMCF_BLOCK + tid);
         };
         // the same with (wave-scope, relaxed) atomic loads, which stay where they are written and cost nothing
         // extra: the prologue must issue in the loop body's order (B before C) or the wait counts derived for the
@@ -427,31 +429,30 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
         auto load_b_pinned = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
 #pragma unroll
             for (int q = 0; q < WQ; ++q) wc[q] = __hip_atomic_load(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            lr = __hip_atomic_load(lrow + (size_t)c * KMCF_BLOCK + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (!IDENT) lr = __hip_atomic_load(lrow + (size_t)c * KMCF_BLOCK + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         };
-        // stage C: x gathers, row data, then the stream (issue order = the order they are waited for)
+        // stage C: x gathers and row data (issue order = the order they are waited for)
         auto load_c = [&](const int4 &d, const int2 &sw, const int (&wc)[WQ], int lr, regs_t &t) {
 #pragma unroll
             for (int q = 0; q < WQ; ++q) t.xr[q] = x[wc[q]];
-            t.valid = lr >= 0;
-            t.row = d.x + (t.valid ? lr : 0);
+            if (IDENT) {
+                t.valid = tid < d.y;
+                t.row = d.x + min(tid, d.y - 1);
+            } else {
+                t.valid = lr >= 0;
+                t.row = d.x + (t.valid ? lr : 0);
+            }
             t.xrow = x[t.row];
             t.dg = diagv[t.row];
             if (SKIP_BOUNDARY) t.valid = t.valid && is_boundary[t.row] == 0;
             t.nq = sw.y;
             t.wn = d.w;
-            if (!ONESET) {
-                const sell_pair *sp = stream + sw.x + lane;
-                const int last = max(sw.y - 1, 0);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) t.pk[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);   // past the wave's end: re-read, a cache hit
-            }
         };
-        sell_pair pk1[ONESET ? NQ : 1];      // ONESET: the one register set of the stream
         int4 d1 = tile4[KMCF_TILE_OF(1)], d2 = tile4[KMCF_TILE_OF(2)];
         int2 s1 = swave[KMCF_TILE_OF(1) * 4 + wv], s2 = swave[KMCF_TILE_OF(2) * 4 + wv];
-        int wca[WQ], wcb[WQ], lra, lrb;
+        int wca[WQ], wcb[WQ], lra = 0, lrb = 0;
         regs_t ta, tb;
+        sell_pair pk[NQ];
         {   // prologue: window maps of tiles 0 and 1, then everything of tile 0 -- the issue order of the loop
             // body (B before C), so that the wait counts the compiler derives for the loop head are the loop's own
             const int4 d0 = tile4[c_first];
@@ -460,15 +461,13 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             load_b_pinned(KMCF_TILE_OF(1), d1, wcb, lrb);
             __builtin_amdgcn_sched_barrier(0);
             load_c(d0, s0, wca, lra, ta);
-            if (ONESET) {
-                const sell_pair *sp = stream + s0.x + lane;
-                const int last = max(s0.y - 1, 0);
+            const sell_pair *sp = stream + s0.x + lane;
+            const int last = max(s0.y - 1, 0);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) pk1[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);
-            }
+            for (int q = 0; q < NQ; ++q) pk[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);
         }
         // wu / lu: window map and lane rows of tile k+1 (loaded an iteration ago); wl / ll: receive tile k+2's.
-        // B is issued before C so that waiting for tile k+1's map next iteration leaves this iteration's stream
+        // B is issued before C so that waiting for tile k+1's map next iteration leaves this iteration's later
         // loads in flight (waits are in issue order).
         auto body = [&](int k, regs_t &cur, regs_t &nxt, double *xb, int (&wu)[WQ], int &lu, int (&wl)[WQ], int &ll) {
             // ---- D(k), first half: products of the window into LDS (slots past the window: 0.0, the padding target)
@@ -483,8 +482,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             load_b(KMCF_TILE_OF(k + 2), d2, wl, ll);
             __builtin_amdgcn_sched_barrier(0);
             load_c(d1, s1, wu, lu, nxt);
-            const sell_pair *spn = stream + s1.x + lane;     // ONESET: tile k+1's stream, requested step by step below
-            const int lastn = max(s1.y - 1, 0);
+            const sell_pair *spn = stream + s1.x + lane;     // tile k+1's stream, requested step by step below
+            const int lastn = max(s1.y - 1, 0);              // (past the wave's end: re-read, a cache hit)
             d1 = d2; s1 = s2;
             d2 = tile4[KMCF_TILE_OF(k + 3)];
             s2 = swave[KMCF_TILE_OF(k + 3) * 4 + wv];
@@ -495,21 +494,14 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (q < cur.nq) {
-                    const sell_pair e = ONESET ? pk1[q] : cur.pk[q];
+                    const sell_pair e = pk[q];
                     const double a0 = *reinterpret_cast<const double *>(base + (e.x & 0xffffu));
                     const double a1 = *reinterpret_cast<const double *>(base + (e.x >> 16));
                     const double a2 = *reinterpret_cast<const double *>(base + (e.y & 0xffffu));
                     const double a3 = *reinterpret_cast<const double *>(base + (e.y >> 16));
                     s += a0; s += a1; s += a2; s += a3;
                 }
-                // ONESET: the register a step has just freed receives the same step of the next tile
-                if (ONESET) pk1[q] = __builtin_nontemporal_load(spn + min(q, lastn) * 64);
-            }
-            // steps past the wave's end were loaded but never read: "use" the last one here, or the compiler finds
-            // their registers still pending at the loop head and drains every load before it reuses one
-            if (!ONESET) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(cur.pk[q]));
+                pk[q] = __builtin_nontemporal_load(spn + min(q, lastn) * 64);
             }
             if (cur.valid) {
                 s += cur.dg * cur.xrow;
@@ -517,9 +509,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
                 if (DOT) dot += cur.xrow * s;
             }
         };
-        // Tiles in pairs (the two register sets swap roles), an odd last tile after the loop: with a conditional
-        // second half inside the loop the compiler sees a path from the first half back to the loop head and
-        // waits there for the stream it has just requested.
+        // Tiles in pairs (the LDS buffers and map registers swap roles), an odd last tile after the loop: with a
+        // conditional second half inside the loop the compiler sees a path from the first half back to the loop
+        // head and waits there for loads it has just requested.
         int k = 0;
         for (; k + 1 < nt; k += 2) {
             body(k, ta, tb, xs, wcb, lrb, wca, lra);
@@ -768,7 +760,7 @@ int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool 
     m->n_sell_tiles, m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, reinterpret_cast<const sell_pair *>(m->d_sell), \
         m->d_p, m->d_Ap, isb, part, m->d_S, chk, m->d_dict, m->d_diagv
 
-template <int NQ, int LW, int ND, bool ONE>
+template <int NQ, int LW, int ND, bool IDENT>
 int sell_dispatch1(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
 {
     hipStream_t st = m->comm->stream;
@@ -779,11 +771,11 @@ int sell_dispatch1(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done
     const int grid = launch ? m->sell_grid : 0;
     int pc = 0;
     if (with_dot) {
-        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, true, true, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
-        else run_or_query(spmv_sell_kernel<NQ, LW, ND, true, false, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, true, true, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        else run_or_query(spmv_sell_kernel<NQ, LW, ND, true, false, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
     } else {
-        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, false, true, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
-        else run_or_query(spmv_sell_kernel<NQ, LW, ND, false, false, ONE>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, false, true, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+        else run_or_query(spmv_sell_kernel<NQ, LW, ND, false, false, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
     }
     return pc;
 }
@@ -791,16 +783,16 @@ int sell_dispatch1(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done
 template <int NQ, int LW, int ND>
 int sell_dispatch(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
 {
-    return m->sell_one ? sell_dispatch1<NQ, LW, ND, true>(m, launch, with_dot, skip_if_done)
-               : sell_dispatch1<NQ, LW, ND, false>(m, launch, with_dot, skip_if_done);
+    return m->sell_ident ? sell_dispatch1<NQ, LW, ND, true>(m, launch, with_dot, skip_if_done)
+                         : sell_dispatch1<NQ, LW, ND, false>(m, launch, with_dot, skip_if_done);
 }
 
 // instantiated (steps, log2 window, dictionary size) triples; dictionaries of one value run as two (second = 0)
 constexpr int KMCF_SELL_NQ[] = {8, 13, 16};
 
-template <int LW>
-int sell_dispatch_lw(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+int sell_dispatch_any(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
 {
+    constexpr int LW = 10;
     const int nd = m->dict_n <= 2 ? 2 : 3;
     switch (m->sell_nq * 10 + nd) {
         case 82: return sell_dispatch<8, LW, 2>(m, launch, with_dot, skip_if_done);
@@ -810,12 +802,6 @@ int sell_dispatch_lw(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_do
         case 162: return sell_dispatch<16, LW, 2>(m, launch, with_dot, skip_if_done);
         default: return sell_dispatch<16, LW, 3>(m, launch, with_dot, skip_if_done);
     }
-}
-
-int sell_dispatch_any(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
-{
-    if (m->sell_lw == 9) return sell_dispatch_lw<9>(m, launch, with_dot, skip_if_done);
-    return sell_dispatch_lw<10>(m, launch, with_dot, skip_if_done);
 }
 
 inline bool sell_active(const kmcf_matrix *m) { return m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3; }
@@ -1024,6 +1010,20 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 // Row-per-lane layout for the coded kernel (spmv_sell_kernel).  Declines (sell_ok stays false, the coded window
 // kernel runs) when a row holds more off-diagonal entries than the largest instantiated register file (4 x 16)
 // or when padding would add more than half to the stream.
+// Tile limits of the row-per-lane layout: window slots per class (slot W - 1 stays empty: the padding entries'
+// target) and rows per tile -- 256 where that still leaves every CU several tiles, fewer on small matrices.
+struct sell_params { int lw, wcap, row_cap; };
+sell_params sell_plan_params(int n)
+{
+    sell_params p;
+    p.lw = 10;
+    p.wcap = (1 << p.lw) - 1;
+    int row_cap = KMCF_BLOCK;
+    while (row_cap > 64 && n / row_cap < 2048) row_cap /= 2;
+    p.row_cap = std::min(KMCF_BLOCK, std::max(64, env_int("KMCF_SPMV_SELL_ROWS", row_cap) / 64 * 64));
+    return p;
+}
+
 int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
 {
     m->sell_ok = false;
@@ -1031,19 +1031,14 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     const int n = m->n_short;
     const std::vector<int> &rp = m->h_row_ptr;
     const std::vector<int> &dpos = m->h_diag_pos;
-    int lw = env_int("KMCF_SPMV_SELL_LW", 10);
-    if (lw != 9 && lw != 10) lw = 10;
-    const int W = 1 << lw, wcap = W - 1;             // slot W - 1 stays empty: the padding entries' target
+    const sell_params sp = sell_plan_params(n);
+    const int lw = sp.lw, W = 1 << lw, wcap = sp.wcap, row_cap = sp.row_cap;
     int maxlen = 0;
     for (int i = 0; i < n; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i] - (dpos[i] >= 0 ? 1 : 0));
     int nq = 0;
     for (int v : KMCF_SELL_NQ)
         if (4 * v >= maxlen) { nq = v; break; }
     if (nq == 0) return KMCF_OK;
-    // rows per tile: 256 where that still leaves every CU several tiles, fewer on small matrices
-    int row_cap = KMCF_BLOCK;
-    while (row_cap > 64 && n / row_cap < 2048) row_cap /= 2;
-    row_cap = std::min(KMCF_BLOCK, std::max(64, env_int("KMCF_SPMV_SELL_ROWS", row_cap) / 64 * 64));
     const unsigned short pad = (unsigned short)((W - 1) << 3);
     std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1), uniq, wcol, ord, pos((size_t)n, 0);
     std::vector<int4> tiles;
@@ -1051,12 +1046,17 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     std::vector<int> lrow;
     std::vector<unsigned short> st;
     int64_t real = 0;
+    bool ident = true;                               // rows already sorted inside every tile (kmcf_sell_refine_order)
     auto len_of = [&](int i) { return rp[i + 1] - rp[i] - (dpos[i] >= 0 ? 1 : 0); };
     int r = 0;
+    size_t next_cut = 0;
+    const std::vector<int> &cuts = m->h_sell_cuts;   // tile ends fixed when the row order was refined (or empty)
     while (r < n) {
         uniq.clear();
         int e = r;
-        while (e < n && e - r < row_cap) {
+        while (next_cut < cuts.size() && cuts[next_cut] <= r) ++next_cut;
+        const int e_max = next_cut < cuts.size() ? std::min(cuts[next_cut], n) : n;
+        while (e < e_max && e - r < row_cap) {
             const size_t before = uniq.size();
             for (int j = rp[e]; j < rp[e + 1]; ++j)
                 if (j != dpos[e] && slot[col[j]] < 0) { slot[col[j]] = 0; uniq.push_back(col[j]); }
@@ -1074,6 +1074,7 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
         ord.resize((size_t)nr);
         for (int i = 0; i < nr; ++i) ord[i] = i;
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len_of(r + a) > len_of(r + b); });
+        for (int i = 0; i < nr; ++i) ident = ident && ord[i] == i;
         tiles.push_back(make_int4(r, nr, (int)wcol.size(), (int)uniq.size()));
         for (int t = 0; t < KMCF_BLOCK; ++t) lrow.push_back(t < nr ? ord[t] : -1);
         for (int w = 0; w < KMCF_BLOCK / 64; ++w) {
@@ -1101,12 +1102,19 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     if (st.size() / 4 > (size_t)0x7fffff00 || (double)st.size() > 1.5 * (double)real + 4096.0 * tiles.size()) return KMCF_OK;
     const int nt = (int)tiles.size();
     if (getenv("KMCF_SPMV_VERBOSE"))
-        fprintf(stderr, "kmcf row-per-lane plan: %d tiles of <= %d rows, %.1f rows, %.1f window columns per tile, %lld entries + %.1f %% padding, %d steps\n",
-                nt, row_cap, double(n) / nt, double(wcol.size()) / nt, (long long)real, 100.0 * (double(st.size()) / double(std::max<int64_t>(real, 1)) - 1.0), nq);
+        fprintf(stderr, "kmcf row-per-lane plan: %d tiles of <= %d rows%s, %.1f rows, %.1f window columns per tile, %lld entries + %.1f %% padding, %d steps\n",
+                nt, row_cap, ident ? " (sorted in place)" : "", double(n) / nt, double(wcol.size()) / nt, (long long)real, 100.0 * (double(st.size()) / double(std::max<int64_t>(real, 1)) - 1.0), nq);
     if (getenv("KMCF_SPMV_VERBOSE")) {
         std::vector<long long> hist(20, 0), rows(20, 0);
         for (const int2 &w : waves) ++hist[std::min(w.y, 19)];
         for (int i = 0; i < n; ++i) ++rows[std::min((len_of(i) + 3) / 4, 19)];
+        long long runs = 0, lines = 0;
+        for (const int4 &t : tiles)
+            for (int q = 0; q < t.w; ++q) {
+                if (q == 0 || wcol[t.z + q] != wcol[t.z + q - 1] + 1) ++runs;
+                if (q == 0 || wcol[t.z + q] / 8 != wcol[t.z + q - 1] / 8) ++lines;
+            }
+        fprintf(stderr, "  window: %.1f runs of consecutive columns, %.1f 64-byte lines of x per tile\n", double(runs) / nt, double(lines) / nt);
         fprintf(stderr, "  steps: waves / rows ");
         for (int q = 0; q < 20; ++q)
             if (hist[q] || rows[q]) fprintf(stderr, " %d: %lld / %lld;", q, hist[q], rows[q]);
@@ -1132,7 +1140,7 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     m->sell_lw = lw;
     m->sell_nq = nq;
     m->sell_dirty = true;
-    m->sell_one = env_int("KMCF_SPMV_SELL_ONE", 1) != 0;
+    m->sell_ident = ident;
     m->sell_ok = true;
     m->sell_grid = 0;                                 // with the dictionary (its size selects the instance)
     return KMCF_OK;
@@ -1445,6 +1453,62 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
 }
 
 // Re-plan the SpMV of an existing matrix from the KMCF_SPMV_* environment (tuning aid).
+// Refines an internal row order for the row-per-lane layout: the rows of each of its tiles (cut exactly as
+// plan_sell will cut them: the cut depends on the rows' column SETS, not on their order inside a tile) are
+// sorted by off-diagonal length, longest first.  Lane t of a tile then owns row r0 + t: x, diagonal and y of a
+// tile are contiguous for the kernel.  cuts receives the end row of every tile: plan_sell must cut there (its
+// own greedy cut would try a DIFFERENT next row after a window-limited tile, the next tile's longest).  rp / col: the caller-ordered local pattern (own columns < n_loc, halo
+// slots above); perm[i] = caller row of internal row i; only the first n_short entries are touched.
+void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *col, std::vector<int> &perm, std::vector<int> &cuts)
+{
+    cuts.clear();
+    if (env_int("KMCF_SPMV_SELL", 1) == 0 || env_int("KMCF_SPMV_SELL_SORT", 1) == 0 || n_short < 2) return;
+    const sell_params sp = sell_plan_params(n_short);
+    std::vector<unsigned char> mark((size_t)n_cols, 0);
+    std::vector<int> uniq, len((size_t)n_short);
+    for (int i = 0; i < n_short; ++i) {
+        const int r = perm[i];
+        bool diag = false;
+        for (int j = rp[r]; j < rp[r + 1] && !diag; ++j) diag = col[j] == r;
+        len[i] = rp[r + 1] - rp[r] - (diag ? 1 : 0);
+    }
+    std::vector<int> ord, tmp;
+    int i = 0;
+    while (i < n_short) {
+        uniq.clear();
+        int e = i;
+        while (e < n_short && e - i < sp.row_cap) {
+            const int r = perm[e];
+            const size_t before = uniq.size();
+            bool diag = false;
+            for (int j = rp[r]; j < rp[r + 1]; ++j) {
+                const int c = col[j];
+                if (c == r && !diag) { diag = true; continue; }
+                if (!mark[c]) { mark[c] = 1; uniq.push_back(c); }
+            }
+            if ((int)uniq.size() > sp.wcap) {
+                for (size_t q = before; q < uniq.size(); ++q) mark[uniq[q]] = 0;
+                uniq.resize(before);
+                break;
+            }
+            ++e;
+        }
+        if (e == i) { cuts.clear(); return; }         // a row alone exceeds a window: no such layout
+        cuts.push_back(e);
+        const int nr = e - i;
+        ord.resize((size_t)nr);
+        for (int t = 0; t < nr; ++t) ord[t] = t;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len[i + a] > len[i + b]; });
+        tmp.resize((size_t)nr);
+        for (int t = 0; t < nr; ++t) tmp[t] = perm[i + ord[t]];
+        std::copy(tmp.begin(), tmp.end(), perm.begin() + i);
+        for (int t = 0; t < nr; ++t) tmp[t] = len[i + ord[t]];
+        std::copy(tmp.begin(), tmp.end(), len.begin() + i);
+        for (int c : uniq) mark[c] = 0;
+        i = e;
+    }
+}
+
 void kmcf_sell_free(kmcf_matrix *m)
 {
     void *ptrs[] = {m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, m->d_sell, m->d_sell_pos};

@@ -181,7 +181,7 @@ def test_full_size_current_and_heat(full, km):
     assert dens >= 0.4, dens
     mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
     minfo = mat.info()
-    assert minfo["spmv_kind"] == 2 and m(info["spmv_coded"] > 0) == bool(CODED_ON)     # long rows did not displace the window kernel
+    assert minfo["spmv_kind"] == 2 and (minfo["spmv_coded"] > 0) == bool(CODED_ON)     # long rows did not displace the window kernel
 
     def tspmv(x):
         p = t.as_tensor(np.ascontiguousarray(x), device="cuda")

@@ -27,7 +27,7 @@ def torch():
 
 
 def _replan(km, mat, monkeypatch, **env):
-    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED", "SELL", "SELL_ROWS", "SELL_LW"):
+    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED", "SELL", "SELL_ROWS"):
         monkeypatch.delenv("KMCF_SPMV_" + k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv("KMCF_SPMV_" + k, str(v))
@@ -74,8 +74,7 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     res = {}
     for name, env in (("window_plain", dict(KIND=2, CODED=0)), ("stream", dict(KIND=1)), ("vec", dict(KIND=0)),
                       ("window_coded", dict(KIND=2, SELL=0)), ("window_u4", dict(KIND=2, U=4, WQ=2, SELL=0)),
-                      ("window_wq4", dict(KIND=2, WQ=4, CODED=0)), ("lane_rows128", dict(KIND=2, SELL=1, SELL_ROWS=128)),
-                      ("lane_lw9", dict(KIND=2, SELL=1, SELL_LW=9))):
+                      ("window_wq4", dict(KIND=2, WQ=4, CODED=0)), ("lane_rows128", dict(KIND=2, SELL=1, SELL_ROWS=128))):
         inf = _replan(km, mat, monkeypatch, **env)
         assert inf["spmv_kind"] == env["KIND"], (name, inf)
         want_coded = 0 if env["KIND"] != 2 or not env.get("CODED", 1) else (2 if env.get("SELL", 1) else 1)
@@ -87,7 +86,6 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     assert np.all(np.abs(res["window_u4"] - res["window_coded"]) <= 1e-15 * bound + 1e-300)   # both coded: diagonal last
     # the row-per-lane kernel adds a row's products in column order, whatever its tiling
     np.testing.assert_array_equal(res["lane_rows128"], y_coded)
-    np.testing.assert_array_equal(res["lane_lw9"], y_coded)
     assert np.all(np.abs(res["window_coded"] - y_coded) <= 4e-16 * 53 * bound)
     assert np.all(np.abs(res["window_plain"] - y_coded) <= 4e-16 * 53 * bound)
 

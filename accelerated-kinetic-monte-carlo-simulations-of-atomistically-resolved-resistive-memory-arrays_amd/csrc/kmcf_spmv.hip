@@ -387,7 +387,7 @@ typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entri
 template <int WQ>
 struct sell_regs {
     double xr[WQ];
-    double xrow, dg;
+    double xrow, xown, dg;             // x of the lane's row; x of row r0 + t (the same thing when IDENT)
     int row, nq, wn;
     bool valid;
 };
@@ -399,7 +399,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S,
     int check_done, const double *__restrict__ dict, const double *__restrict__ diagv)
 {
-    constexpr int W = 1 << LW, WQ = W / KMCF_BLOCK, BUF = ND * W;
+    // window slots [0, 256): the tile's own rows (slot t = x[r0 + t], which the lane loads anyway); the rest:
+    // the other columns the tile references, gathered through wcol
+    constexpr int W = 1 << LW, WQ = W / KMCF_BLOCK - 1, BUF = ND * W;
     typedef sell_regs<WQ> regs_t;
     __shared__ double xs[2 * BUF];      // (exactly 32 KB for two values and 1024 slots: five blocks fill a CU's LDS)
     if (check_done && S->done) return;
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
                 t.row = d.x + (t.valid ? lr : 0);
             }
             t.xrow = x[t.row];
+            t.xown = IDENT ? t.xrow : x[d.x + min(tid, d.y - 1)];
             t.dg = diagv[t.row];
             if (SKIP_BOUNDARY) t.valid = t.valid && is_boundary[t.row] == 0;
             t.nq = sw.y;
@@ -472,11 +475,13 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
         auto body = [&](int k, regs_t &cur, regs_t &nxt, double *xb, int (&wu)[WQ], int &lu, int (&wl)[WQ], int &ll) {
             // ---- D(k), first half: products of the window into LDS (slots past the window: 0.0, the padding target)
 #pragma unroll
+            for (int c = 0; c < ND; ++c) xb[c * W + tid] = dv[c] * cur.xown;
+#pragma unroll
             for (int q = 0; q < WQ; ++q) {
                 const int slot = q * KMCF_BLOCK + tid;
                 const double v = slot < cur.wn ? cur.xr[q] : 0.0;
 #pragma unroll
-                for (int c = 0; c < ND; ++c) xb[c * W + slot] = dv[c] * v;
+                for (int c = 0; c < ND; ++c) xb[c * W + KMCF_BLOCK + slot] = dv[c] * v;
             }
             // ---- B(k+2), C(k+1), A(k+3)
             load_b(KMCF_TILE_OF(k + 2), d2, wl, ll);
@@ -1010,18 +1015,53 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 // Row-per-lane layout for the coded kernel (spmv_sell_kernel).  Declines (sell_ok stays false, the coded window
 // kernel runs) when a row holds more off-diagonal entries than the largest instantiated register file (4 x 16)
 // or when padding would add more than half to the stream.
-// Tile limits of the row-per-lane layout: window slots per class (slot W - 1 stays empty: the padding entries'
-// target) and rows per tile -- 256 where that still leaves every CU several tiles, fewer on small matrices.
-struct sell_params { int lw, wcap, row_cap; };
+// Tile limits of the row-per-lane layout: window slots per class (the first 256 are the tile's own rows, slot
+// W - 1 stays empty: the padding entries' target) and rows per tile -- 256 where that still leaves every CU several tiles, fewer on small matrices.
+struct sell_params { int lw, ecap, row_cap; };
 sell_params sell_plan_params(int n)
 {
     sell_params p;
     p.lw = 10;
-    p.wcap = (1 << p.lw) - 1;
+    p.ecap = (1 << p.lw) - KMCF_BLOCK - 1;          // columns outside the tile's own rows
     int row_cap = KMCF_BLOCK;
     while (row_cap > 64 && n / row_cap < 2048) row_cap /= 2;
     p.row_cap = std::min(KMCF_BLOCK, std::max(64, env_int("KMCF_SPMV_SELL_ROWS", row_cap) / 64 * 64));
     return p;
+}
+
+// One tile of the row-per-lane layout, cut greedily from position `start`: rows are added while the tile holds at
+// most row_cap rows and references at most ecap columns OUTSIDE itself (its own rows are window slots 0..255 for
+// free).  row_id(e): column id of position e's row; cols(e, f): calls f(c) for the off-diagonal columns of
+// position e.  mark: per column id, bit 0 = referenced by the tile, bit 1 = row of the tile; `touched` lists
+// the referenced ids.  The caller clears the marks of `touched` and of the tile's rows afterwards.
+template <class RowId, class Cols>
+int sell_cut_tile(int start, int e_max, int row_cap, int ecap, RowId row_id, Cols cols, std::vector<unsigned char> &mark,
+                  std::vector<int> &touched)
+{
+    touched.clear();
+    int e = start, ext = 0;
+    while (e < e_max && e - start < row_cap) {
+        const int id = row_id(e);
+        const size_t before = touched.size();
+        int next = ext - ((mark[id] & 1) ? 1 : 0);          // referenced from inside so far: now one of the tile's own
+        mark[id] |= 2;
+        cols(e, [&](int c) {
+            if (!(mark[c] & 1)) {
+                mark[c] |= 1;
+                touched.push_back(c);
+                if (!(mark[c] & 2)) ++next;
+            }
+        });
+        if (next > ecap) {
+            for (size_t q = before; q < touched.size(); ++q) mark[touched[q]] &= (unsigned char)~1;
+            touched.resize(before);
+            mark[id] &= (unsigned char)~2;
+            break;
+        }
+        ext = next;
+        ++e;
+    }
+    return e;
 }
 
 int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
@@ -1032,7 +1072,7 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     const std::vector<int> &rp = m->h_row_ptr;
     const std::vector<int> &dpos = m->h_diag_pos;
     const sell_params sp = sell_plan_params(n);
-    const int lw = sp.lw, W = 1 << lw, wcap = sp.wcap, row_cap = sp.row_cap;
+    const int lw = sp.lw, W = 1 << lw, row_cap = sp.row_cap;
     int maxlen = 0;
     for (int i = 0; i < n; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i] - (dpos[i] >= 0 ? 1 : 0));
     int nq = 0;
@@ -1040,7 +1080,8 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
         if (4 * v >= maxlen) { nq = v; break; }
     if (nq == 0) return KMCF_OK;
     const unsigned short pad = (unsigned short)((W - 1) << 3);
-    std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1), uniq, wcol, ord, pos((size_t)n, 0);
+    std::vector<int> slot((size_t)m->n_loc + m->n_halo, -1), uniq, touched, wcol, ord, pos((size_t)n, 0);
+    std::vector<unsigned char> mark((size_t)m->n_loc + m->n_halo, 0);
     std::vector<int4> tiles;
     std::vector<int2> waves;
     std::vector<int> lrow;
@@ -1052,24 +1093,24 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     size_t next_cut = 0;
     const std::vector<int> &cuts = m->h_sell_cuts;   // tile ends fixed when the row order was refined (or empty)
     while (r < n) {
-        uniq.clear();
-        int e = r;
         while (next_cut < cuts.size() && cuts[next_cut] <= r) ++next_cut;
         const int e_max = next_cut < cuts.size() ? std::min(cuts[next_cut], n) : n;
-        while (e < e_max && e - r < row_cap) {
-            const size_t before = uniq.size();
-            for (int j = rp[e]; j < rp[e + 1]; ++j)
-                if (j != dpos[e] && slot[col[j]] < 0) { slot[col[j]] = 0; uniq.push_back(col[j]); }
-            if ((int)uniq.size() > wcap) {
-                for (size_t q = before; q < uniq.size(); ++q) slot[uniq[q]] = -1;
-                uniq.resize(before);
-                break;
-            }
-            ++e;
-        }
+        const int e = sell_cut_tile(r, e_max, row_cap, sp.ecap, [](int i) { return i; },
+                                    [&](int i, auto f) {
+                                        for (int j = rp[i]; j < rp[i + 1]; ++j)
+                                            if (j != dpos[i]) f(col[j]);
+                                    },
+                                    mark, touched);
         if (e == r) return KMCF_OK;                  // (cannot happen: a row holds <= 64 entries)
+        uniq.clear();
+        for (int c : touched) {
+            if (c >= r && c < e) slot[c] = c - r;    // one of the tile's rows: its slot is its lane
+            else uniq.push_back(c);
+            mark[c] = 0;
+        }
+        for (int i = r; i < e; ++i) mark[i] = 0;
         std::sort(uniq.begin(), uniq.end());
-        for (size_t q = 0; q < uniq.size(); ++q) slot[uniq[q]] = (int)q;
+        for (size_t q = 0; q < uniq.size(); ++q) slot[uniq[q]] = KMCF_BLOCK + (int)q;
         const int nr = e - r;
         ord.resize((size_t)nr);
         for (int i = 0; i < nr; ++i) ord[i] = i;
@@ -1095,7 +1136,7 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
                 real += k;
             }
         }
-        for (int cj : uniq) slot[cj] = -1;
+        for (int cj : touched) slot[cj] = -1;
         wcol.insert(wcol.end(), uniq.begin(), uniq.end());
         r = e;
     }
@@ -1465,7 +1506,7 @@ void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *c
     if (env_int("KMCF_SPMV_SELL", 1) == 0 || env_int("KMCF_SPMV_SELL_SORT", 1) == 0 || n_short < 2) return;
     const sell_params sp = sell_plan_params(n_short);
     std::vector<unsigned char> mark((size_t)n_cols, 0);
-    std::vector<int> uniq, len((size_t)n_short);
+    std::vector<int> touched, len((size_t)n_short);
     for (int i = 0; i < n_short; ++i) {
         const int r = perm[i];
         bool diag = false;
@@ -1475,24 +1516,18 @@ void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *c
     std::vector<int> ord, tmp;
     int i = 0;
     while (i < n_short) {
-        uniq.clear();
-        int e = i;
-        while (e < n_short && e - i < sp.row_cap) {
-            const int r = perm[e];
-            const size_t before = uniq.size();
-            bool diag = false;
-            for (int j = rp[r]; j < rp[r + 1]; ++j) {
-                const int c = col[j];
-                if (c == r && !diag) { diag = true; continue; }
-                if (!mark[c]) { mark[c] = 1; uniq.push_back(c); }
-            }
-            if ((int)uniq.size() > sp.wcap) {
-                for (size_t q = before; q < uniq.size(); ++q) mark[uniq[q]] = 0;
-                uniq.resize(before);
-                break;
-            }
-            ++e;
-        }
+        const int e = sell_cut_tile(i, n_short, sp.row_cap, sp.ecap, [&](int q) { return perm[q]; },
+                                    [&](int q, auto f) {
+                                        const int r = perm[q];
+                                        bool diag = false;
+                                        for (int j = rp[r]; j < rp[r + 1]; ++j) {
+                                            if (col[j] == r && !diag) { diag = true; continue; }
+                                            f(col[j]);
+                                        }
+                                    },
+                                    mark, touched);
+        for (int c : touched) mark[c] = 0;
+        for (int q = i; q < e; ++q) mark[perm[q]] = 0;
         if (e == i) { cuts.clear(); return; }         // a row alone exceeds a window: no such layout
         cuts.push_back(e);
         const int nr = e - i;
@@ -1504,7 +1539,6 @@ void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *c
         std::copy(tmp.begin(), tmp.end(), perm.begin() + i);
         for (int t = 0; t < nr; ++t) tmp[t] = len[i + ord[t]];
         std::copy(tmp.begin(), tmp.end(), len.begin() + i);
-        for (int c : uniq) mark[c] = 0;
         i = e;
     }
 }

@@ -108,11 +108,26 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
                                                           double tol2, int check_tol)
 {
     __shared__ double lds4[4];
-    if (S->done) return;
+    // Everything this block needs is requested before anything is waited for (scalars, the partial sums of the
+    // previous kernel, the block's first elements): a block lives for one or two elements per lane, so a chain of
+    // dependent loads in front of its stream would be most of its life.
+    const int n2 = n >> 1;
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *d2 = reinterpret_cast<const double2 *>(dinv);
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const int i0 = blockIdx.x * KMCF_BLOCK + threadIdx.x;
+    const int done = S->done;
+    const double rz_prev = S->rz[parity ^ 1], bb_saved = S->bb;
+    double2 z0 = make_double2(0.0, 0.0), dv0 = make_double2(1.0, 1.0), pv0 = make_double2(0.0, 0.0);
+    if (!first && i0 < n2) {
+        z0 = r2[i0];
+        if (PRECOND) dv0 = d2[i0];
+        pv0 = p2[i0];
+    }
     const double rz_new = reduce_partials(prz, lds4);
+    if (done) return;
     double bb;
     if (first) bb = reduce_partials(pbb, lds4);
-    else bb = S->bb;
+    else bb = bb_saved;
     // check_tol: 0 fixed iteration count; 1 relative rule r.z/b.b > tol^2 (:217);
     // 2 absolute rule of solve_sparse_CG_Jacobi (src/iterative_solvers_gpu.cu:838-840, 858):
     //   first test on ||r|| (hipblasDnrm2), later ones on ||r||^2 (hipblasDdot)
@@ -127,9 +142,6 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
     }
     if (!go) return;
     // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned)
-    const int n2 = n >> 1;
-    const double2 *r2 = reinterpret_cast<const double2 *>(r), *d2 = reinterpret_cast<const double2 *>(dinv);
-    double2 *p2 = reinterpret_cast<double2 *>(p);
     if (first) {
         for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
             double2 rv = r2[i];
@@ -138,12 +150,18 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = PRECOND ? r[n - 1] * dinv[n - 1] : r[n - 1];
     } else {
-        const double beta = rz_new / S->rz[parity ^ 1];                    // :220
-        for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
+        const double beta = rz_new / rz_prev;                              // :220
+        if (i0 < n2) {                                                     // (the prefetched element)
+            if (PRECOND) { z0.x *= dv0.x; z0.y *= dv0.y; }
+            pv0.x = beta * pv0.x + z0.x;                                   // :221 dscal, :222 daxpy
+            pv0.y = beta * pv0.y + z0.y;
+            p2[i0] = pv0;
+        }
+        for (int i = i0 + gridDim.x * KMCF_BLOCK; i < n2; i += gridDim.x * KMCF_BLOCK) {
             double2 z = r2[i];
             if (PRECOND) { const double2 dv = d2[i]; z.x *= dv.x; z.y *= dv.y; }
             double2 pv = p2[i];
-            pv.x = beta * pv.x + z.x;                                      // :221 dscal, :222 daxpy
+            pv.x = beta * pv.x + z.x;
             pv.y = beta * pv.y + z.y;
             p2[i] = pv;
         }
@@ -163,17 +181,38 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
                                                            double *__restrict__ part_rz)
 {
     __shared__ double lds4[4];
-    if (S->done) return;
-    const double pAp = reduce_partials(ppap, lds4);
-    const double a = S->rz[parity] / pAp;
-    const double na = -a;
-    double rz = 0.0;
-    // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned)
+    // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned);
+    // scalars, partial sums and the block's first elements are all requested before the first wait (cg_p_kernel)
     const int n2 = n >> 1;
     double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
     const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap),
                   *d2 = reinterpret_cast<const double2 *>(dinv);
-    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
+    const int i0 = blockIdx.x * KMCF_BLOCK + threadIdx.x;
+    const int done = S->done;
+    const double rz_cur = S->rz[parity];
+    double2 xv0 = make_double2(0.0, 0.0), pv0 = xv0, av0 = xv0, rv0 = xv0, dv0 = make_double2(1.0, 1.0);
+    if (i0 < n2) {
+        xv0 = x2[i0]; pv0 = p2[i0]; av0 = A2[i0]; rv0 = r2[i0];
+        if (PRECOND) dv0 = d2[i0];
+    }
+    const double pAp = reduce_partials(ppap, lds4);
+    if (done) return;
+    const double a = rz_cur / pAp;
+    const double na = -a;
+    double rz = 0.0;
+    if (i0 < n2) {                                  // (the prefetched element; same operations as the loop's)
+        xv0.x = xv0.x + a * pv0.x;
+        xv0.y = xv0.y + a * pv0.y;
+        x2[i0] = xv0;
+        rv0.x = rv0.x + na * av0.x;
+        rv0.y = rv0.y + na * av0.y;
+        r2[i0] = rv0;
+        double2 z = rv0;
+        if (PRECOND) { z.x *= dv0.x; z.y *= dv0.y; }
+        rz += rv0.x * z.x;
+        rz += rv0.y * z.y;
+    }
+    for (int i = i0 + gridDim.x * KMCF_BLOCK; i < n2; i += gridDim.x * KMCF_BLOCK) {
         double2 xv = x2[i];
         const double2 pv = p2[i], av = A2[i];
         double2 rv = r2[i];

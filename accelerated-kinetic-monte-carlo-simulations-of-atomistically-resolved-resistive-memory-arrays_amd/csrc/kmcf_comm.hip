@@ -125,6 +125,8 @@ extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int ran
     KMCF_HIP(hipEventCreate(&c->ev_t1));
     KMCF_HIP(hipEventCreate(&c->ev_a0));
     KMCF_HIP(hipEventCreate(&c->ev_a1));
+    KMCF_HIP(hipEventCreate(&c->ev_call0));
+    KMCF_HIP(hipEventCreate(&c->ev_call1));
     KMCF_HIP(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), 1024 * sizeof(double)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 16 * sizeof(int), hipHostMallocDefault));
@@ -255,6 +257,8 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
     if (c->ev_a0) hipEventDestroy(c->ev_a0);
     if (c->ev_a1) hipEventDestroy(c->ev_a1);
+    if (c->ev_call0) hipEventDestroy(c->ev_call0);
+    if (c->ev_call1) hipEventDestroy(c->ev_call1);
     if (c->ev_entry) hipEventDestroy(c->ev_entry);
     if (c->d_scratch) hipFree(c->d_scratch);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -292,6 +296,10 @@ int kmcf_enter(kmcf_comm *c)
 {
     KMCF_CHECK(c && c->device >= 0, KMCF_ERR_STATE, "host-only communicator");
     KMCF_HIP(hipSetDevice(c->device));
+    // nothing queued on the caller's stream (the usual case: the caller has just synchronised): nothing to order
+    // against -- an event on the legacy null stream is not cheap
+    if (!getenv("KMCF_ENTER_ALWAYS") && hipStreamQuery(c->caller_stream) == hipSuccess) return KMCF_OK;
+    (void)hipGetLastError();                          // (hipErrorNotReady is the expected answer otherwise)
     KMCF_HIP(hipEventRecord(c->ev_entry, c->caller_stream));
     KMCF_HIP(hipStreamWaitEvent(c->stream, c->ev_entry, 0));
     return KMCF_OK;

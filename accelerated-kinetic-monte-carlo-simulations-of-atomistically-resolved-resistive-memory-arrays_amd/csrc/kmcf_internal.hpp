@@ -90,6 +90,7 @@ struct kmcf_comm {
     hipEvent_t ev_halo = nullptr;       // comm -> compute
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;   // assembly timing (kmcf_background_potential_sparse)
+    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;   // first / last device work of a kmcf_pcg_jacobi call
     hipEvent_t ev_entry = nullptr;      // caller's stream -> compute stream at every entry point (kmcf_enter)
     hipStream_t caller_stream = nullptr;  // stream the caller's own work is queued on (default: legacy null stream)
     double *d_scratch = nullptr;        // 1024 doubles of persistent scratch (heat reduction partials)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline iterations (0 = auto, ~10-30 s)")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--diag-solves", type=int, default=0, help="after the timed region: time N more solves piecewise (stderr)")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "p2p", "p2p-only"],
                     help="multi-rank data path: auto = peer-to-peer windows if they come up, else RCCL; p2p-only = no RCCL at "
                          "all (rehearsal of N ranks on fewer GPUs, where RCCL refuses to run)")
@@ -148,6 +149,16 @@ def main():
         dist.broadcast(pick, src=0)
         comm.select_transport(int(pick.item()))
     elapsed, st = timed_solve(args.steps, args.warmup)
+    for _ in range(args.diag_solves):           # tuning aid: where a solve's wall time goes
+        r, x, dinv = fresh_vectors()
+        barrier()
+        ta = time.perf_counter()
+        st2 = S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=args.steps)
+        tb = time.perf_counter()
+        barrier()
+        tc = time.perf_counter()
+        sys.stderr.write("diag solve: call %.1f us, trailing barrier %.1f us, device %.1f us\n"
+                         % ((tb - ta) * 1e6, (tc - tb) * 1e6, st2["ms_solve"] * 1e3))
 
     # ---- roofline of the dominant kernel: CSR SpMV (+ fused p.Ap) -------------------------
     # HIP events on the library's compute stream (kmcf_spmv_bench), this rank's rows

@@ -176,7 +176,8 @@ typedef struct {
     double relres;        /* sqrt(rz/bb), dist_conjugate_gradient.cpp:273                */
     double bb;            /* ||b||^2 (all ranks)                                        */
     double rz;            /* last r.z                                                   */
-    float ms_solve;       /* device time of the CG loop (HIP events, compute stream)    */
+    float ms_solve;       /* device time (HIP events, compute stream): of the CG loop; kmcf_pcg_jacobi: of everything
+                           * the call enqueued (vectors in, r = b - A x0, the iterations, vectors out) */
     float ms_assembly;    /* device time of the assembly kernels (K solve only)         */
 } kmcf_solve_stats_t;
 

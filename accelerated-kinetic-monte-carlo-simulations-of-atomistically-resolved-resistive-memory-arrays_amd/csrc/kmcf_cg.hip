@@ -100,12 +100,15 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_finalize_kernel(part_ref p0, in
     }
 }
 
-// Loop head of iteration k: stopping rule, beta, p = z + beta p   (:217-227)
+// Loop head of iteration k: stopping rule, beta, p = z + beta p   (:217-227) -- and the x += alpha p of iteration
+// k-1 (:243), which is applied HERE, where the old p is read anyway: the residual kernel does not touch x and p
+// (80 instead of 88 bytes per row and iteration; the same operation on the same operands, one kernel later).
+// An update still pending when the loop ends is applied by cg_x_kernel or by the caller's output kernel.
 template <bool PRECOND>
 __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restrict__ p, const double *__restrict__ r,
                                                           const double *__restrict__ dinv, part_ref prz, part_ref pbb,
                                                           kmcf_scalars *__restrict__ S, int parity, int first,
-                                                          double tol2, int check_tol)
+                                                          double tol2, int check_tol, double *__restrict__ x)
 {
     __shared__ double lds4[4];
     // Everything this block needs is requested before anything is waited for (scalars, the partial sums of the
@@ -117,11 +120,15 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
     const int i0 = blockIdx.x * KMCF_BLOCK + threadIdx.x;
     const int done = S->done;
     const double rz_prev = S->rz[parity ^ 1], bb_saved = S->bb;
-    double2 z0 = make_double2(0.0, 0.0), dv0 = make_double2(1.0, 1.0), pv0 = make_double2(0.0, 0.0);
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    const int pending = S->x_pending;
+    const double xa = S->xa;
+    double2 z0 = make_double2(0.0, 0.0), dv0 = make_double2(1.0, 1.0), pv0 = make_double2(0.0, 0.0), xv0 = pv0;
     if (!first && i0 < n2) {
         z0 = r2[i0];
         if (PRECOND) dv0 = d2[i0];
         pv0 = p2[i0];
+        if (pending) xv0 = x2[i0];
     }
     const double rz_new = reduce_partials(prz, lds4);
     if (done) return;
@@ -140,7 +147,21 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
         if (go) { S->rz[parity] = rz_new; S->iters += 1; }
         else S->done = 1;
     }
-    if (!go) return;
+    if (!go) {
+        // the last iteration's x += alpha p, then nothing more (later kernels see S->done)
+        if (pending) {
+            if (i0 < n2) { xv0.x = xv0.x + xa * pv0.x; xv0.y = xv0.y + xa * pv0.y; x2[i0] = xv0; }
+            for (int i = i0 + gridDim.x * KMCF_BLOCK; i < n2; i += gridDim.x * KMCF_BLOCK) {
+                double2 xv = x2[i];
+                const double2 pv = p2[i];
+                xv.x = xv.x + xa * pv.x;
+                xv.y = xv.y + xa * pv.y;
+                x2[i] = xv;
+            }
+            if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = x[n - 1] + xa * p[n - 1];
+        }
+        return;
+    }
     // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned)
     if (first) {
         for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n2; i += gridDim.x * KMCF_BLOCK) {
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
     } else {
         const double beta = rz_new / rz_prev;                              // :220
         if (i0 < n2) {                                                     // (the prefetched element)
+            if (pending) { xv0.x = xv0.x + xa * pv0.x; xv0.y = xv0.y + xa * pv0.y; x2[i0] = xv0; }   // :243 of k-1
             if (PRECOND) { z0.x *= dv0.x; z0.y *= dv0.y; }
             pv0.x = beta * pv0.x + z0.x;                                   // :221 dscal, :222 daxpy
             pv0.y = beta * pv0.y + z0.y;
@@ -161,21 +183,27 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
             double2 z = r2[i];
             if (PRECOND) { const double2 dv = d2[i]; z.x *= dv.x; z.y *= dv.y; }
             double2 pv = p2[i];
+            if (pending) {
+                double2 xv = x2[i];
+                xv.x = xv.x + xa * pv.x;
+                xv.y = xv.y + xa * pv.y;
+                x2[i] = xv;
+            }
             pv.x = beta * pv.x + z.x;
             pv.y = beta * pv.y + z.y;
             p2[i] = pv;
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const double z = PRECOND ? r[n - 1] * dinv[n - 1] : r[n - 1];
+            if (pending) x[n - 1] = x[n - 1] + xa * p[n - 1];
             p[n - 1] = beta * p[n - 1] + z;
         }
     }
 }
 
-// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; z = r .* dinv ; partial r.z   (:243-264)
+// alpha = rz/pAp ; r -= alpha Ap ; z = r .* dinv ; partial r.z   (:243-264); x += alpha p is left pending (cg_p_kernel)
 template <bool PRECOND>
-__global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__restrict__ x, double *__restrict__ r,
-                                                           const double *__restrict__ p, const double *__restrict__ Ap,
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__restrict__ r, const double *__restrict__ Ap,
                                                            const double *__restrict__ dinv, part_ref ppap,
                                                            kmcf_scalars *__restrict__ S, int parity,
                                                            double *__restrict__ part_rz)
@@ -184,15 +212,14 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
     // two elements per lane and step (16-byte loads and stores; the workspace vectors are 256-byte aligned);
     // scalars, partial sums and the block's first elements are all requested before the first wait (cg_p_kernel)
     const int n2 = n >> 1;
-    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
-    const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap),
-                  *d2 = reinterpret_cast<const double2 *>(dinv);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *A2 = reinterpret_cast<const double2 *>(Ap), *d2 = reinterpret_cast<const double2 *>(dinv);
     const int i0 = blockIdx.x * KMCF_BLOCK + threadIdx.x;
     const int done = S->done;
     const double rz_cur = S->rz[parity];
-    double2 xv0 = make_double2(0.0, 0.0), pv0 = xv0, av0 = xv0, rv0 = xv0, dv0 = make_double2(1.0, 1.0);
+    double2 av0 = make_double2(0.0, 0.0), rv0 = av0, dv0 = make_double2(1.0, 1.0);
     if (i0 < n2) {
-        xv0 = x2[i0]; pv0 = p2[i0]; av0 = A2[i0]; rv0 = r2[i0];
+        av0 = A2[i0]; rv0 = r2[i0];
         if (PRECOND) dv0 = d2[i0];
     }
     const double pAp = reduce_partials(ppap, lds4);
@@ -201,9 +228,6 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
     const double na = -a;
     double rz = 0.0;
     if (i0 < n2) {                                  // (the prefetched element; same operations as the loop's)
-        xv0.x = xv0.x + a * pv0.x;
-        xv0.y = xv0.y + a * pv0.y;
-        x2[i0] = xv0;
         rv0.x = rv0.x + na * av0.x;
         rv0.y = rv0.y + na * av0.y;
         r2[i0] = rv0;
@@ -213,12 +237,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
         rz += rv0.y * z.y;
     }
     for (int i = i0 + gridDim.x * KMCF_BLOCK; i < n2; i += gridDim.x * KMCF_BLOCK) {
-        double2 xv = x2[i];
-        const double2 pv = p2[i], av = A2[i];
+        const double2 av = A2[i];
         double2 rv = r2[i];
-        xv.x = xv.x + a * pv.x;
-        xv.y = xv.y + a * pv.y;
-        x2[i] = xv;
         rv.x = rv.x + na * av.x;
         rv.y = rv.y + na * av.y;
         r2[i] = rv;
@@ -229,7 +249,6 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int i = n - 1;
-        x[i] = x[i] + a * p[i];
         const double ri = r[i] + na * Ap[i];
         r[i] = ri;
         const double z = PRECOND ? ri * dinv[i] : ri;
@@ -238,8 +257,17 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_xr_kernel(int n, double *__rest
     double t = block_sum(rz, lds4);
     if (threadIdx.x == 0) {
         part_rz[blockIdx.x] = t;
-        if (blockIdx.x == 0) S->pAp = pAp;
+        if (blockIdx.x == 0) { S->pAp = pAp; S->xa = a; S->x_pending = 1; }
     }
+}
+
+// The x += alpha p still pending when the loop ended on its iteration limit.
+__global__ __launch_bounds__(KMCF_BLOCK) void cg_x_kernel(int n, double *__restrict__ x, const double *__restrict__ p,
+                                                          const kmcf_scalars *__restrict__ S)
+{
+    if (S->done || !S->x_pending) return;
+    const double a = S->xa;
+    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) x[i] = x[i] + a * p[i];
 }
 
 // After the loop: the r.z the reference prints (:273) if the loop did not end on the stopping rule.
@@ -329,7 +357,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
             const int k = launched + i + 1;  // reference's k
             const int parity = k & 1;
             cg_p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_p, m->d_r, m->d_dinv, prz, pbb, S, parity,
-                                                            k == 1 ? 1 : 0, tol2, check_tol);
+                                                            k == 1 ? 1 : 0, tol2, check_tol, m->d_x);
             KMCF_HIP(hipGetLastError());
             KMCF_TRY(kmcf_spmv_device(m, true, true));
             if (multi) {
@@ -337,8 +365,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
                 KMCF_HIP(hipGetLastError());
                 KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[2], 1));
             }
-            cg_xr_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_p, m->d_Ap, m->d_dinv, ppap, S,
-                                                             parity, m->d_part_b);
+            cg_xr_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, ppap, S, parity, m->d_part_b);
             KMCF_HIP(hipGetLastError());
             if (multi) {
                 cg_finalize_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz_loc, 0, pr_none(), -1, S, 1);
@@ -358,6 +385,10 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     if (!done) {
         cg_tail_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz, S);
         KMCF_HIP(hipGetLastError());
+        if (!(flags & 2)) {                        // (with flag 2 the caller's output kernel applies it on its way)
+            cg_x_kernel<<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_p, S);
+            KMCF_HIP(hipGetLastError());
+        }
     }
     KMCF_HIP(hipEventRecord(c->ev_t1, st));
     if (flags & 2) return KMCF_OK;                 // the caller's output kernel writes the scalars to the host
@@ -670,17 +701,23 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_in_kernel(int n, const int *__r
     }
 }
 __global__ __launch_bounds__(KMCF_BLOCK) void cg_out_kernel(int n, const int *__restrict__ perm, const double *__restrict__ r,
-                                                            const double *__restrict__ x, double *__restrict__ r_u, double *__restrict__ x_u,
+                                                            const double *__restrict__ x, const double *__restrict__ p,
+                                                            double *__restrict__ r_u, double *__restrict__ x_u,
                                                             const kmcf_scalars *__restrict__ S, kmcf_scalars *__restrict__ host_S)
 {
     // the solve's scalars straight into pinned host memory: a 120-byte hipMemcpyAsync costs tens of microseconds
     if (host_S && blockIdx.x == 0 && threadIdx.x == 0) *host_S = *S;
+    // a loop that ended on its iteration limit has left its last x += alpha p to this kernel (cg_p_kernel)
+    const bool pending = !S->done && S->x_pending;
+    const double a = S->xa;
     int first, end, stride;
     xcd_range(n, first, end, stride);
     for (int i = first; i < end; i += stride) {
         const int s = perm ? perm[i] : i;
         r_u[s] = r[i];
-        x_u[s] = x[i];
+        double xv = x[i];
+        if (pending) xv = xv + a * p[i];
+        x_u[s] = xv;
     }
 }
 inline int perm_grid(int n) { return (vec_grid(n) + 7) / 8 * 8; }
@@ -713,7 +750,7 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     }
     KMCF_TRY(pcg_workspace_flags(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats, 1 | 2));
     const double t_b = trace ? now() : 0.0;
-    cg_out_kernel<<<perm_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, d_r, d_x, m->d_S, c->h_scal);
+    cg_out_kernel<<<perm_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, m->d_p, d_r, d_x, m->d_S, c->h_scal);
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipEventRecord(c->ev_call1, c->stream));
     // results visible on return (:271 hipDeviceSynchronize)

@@ -55,7 +55,9 @@ struct kmcf_scalars {
     double alpha[2];  // single-reduction CG: step length ping-pong by iteration parity
     int done;         // stopping rule met
     int iters;        // iterations executed
-    int pad[2];
+    int x_pending;    // classic loop: x += xa * p of the last iteration is still to be applied (cg_p / cg_x / cg_out)
+    int pad;
+    double xa;        // ... its step length
 };
 
 struct kmcf_matrix;

@@ -308,18 +308,35 @@ int kmcf_enter(kmcf_comm *c)
 // ------------------------------------------------------------------ loopback transport (tests)
 namespace {
 
-void group_barrier(kmcf_group *g)
+// Bounded: a rank that never arrives (its thread failed in an earlier call and left) must not hang the others.
+// After one expiry the group is broken and every later barrier fails at once.
+bool group_barrier_wait(kmcf_group *g)
 {
+    static const int timeout_s = getenv("KMCF_LOOPBACK_TIMEOUT_S") ? atoi(getenv("KMCF_LOOPBACK_TIMEOUT_S")) : 120;
     std::unique_lock<std::mutex> lk(g->mu);
+    if (g->broken) return false;
     const long gen = g->generation;
     if (++g->arrived == g->nranks) {
         g->arrived = 0;
         ++g->generation;
         g->cv.notify_all();
-    } else {
-        g->cv.wait(lk, [&] { return g->generation != gen; });
+        return true;
     }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return g->generation != gen || g->broken; }) || g->broken) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return true;
 }
+
+#define group_barrier(g)                                                                                          \
+    do {                                                                                                          \
+        if (!group_barrier_wait(g)) {                                                                             \
+            kmcf_set_error("loopback group: a rank did not arrive at a collective (it failed earlier, or timed out)"); \
+            return KMCF_ERR_COMM;                                                                                 \
+        }                                                                                                         \
+    } while (0)
 
 int loopback_allreduce(kmcf_comm *c, double *d_buf, int count)
 {

@@ -62,6 +62,7 @@ struct kmcf_scalars {
 
 struct kmcf_matrix;
 
+
 // In-process "loopback" group: the P ranks are P host threads of ONE process sharing one GPU.
 // Transport for testing the multi-rank logic (halo maps, boundary pass, reductions) on a 1-GPU
 // box, where RCCL refuses two ranks on one device.  Host-synchronous, not a performance path.
@@ -71,6 +72,7 @@ struct kmcf_group {
     std::condition_variable cv;
     int arrived = 0;
     long generation = 0;
+    bool broken = false;               // a barrier timed out: the group is unusable
     std::vector<void *> slot;            // per-rank published pointer
     std::vector<kmcf_matrix *> mat;      // per-rank matrix taking part in the current halo exchange
     int refs = 0;

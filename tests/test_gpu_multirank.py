@@ -74,7 +74,7 @@ def _run_ranks(km, d, P, ref_charge, expect_transport="loopback"):
             import traceback
             errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
     for t in threads:
         t.start()
     for t in threads:
@@ -217,7 +217,7 @@ def test_multirank_generic_matrix_small_and_empty_ranks(km, n, P):
             import traceback
             errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
     for t in threads:
         t.start()
     for t in threads:

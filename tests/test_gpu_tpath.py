@@ -260,7 +260,7 @@ def test_small_device_multirank(km, oracle, torch, P):
             import traceback
             errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
     for t in threads:
         t.start()
     for t in threads:

@@ -1016,15 +1016,17 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
 // kernel runs) when a row holds more off-diagonal entries than the largest instantiated register file (4 x 16)
 // or when padding would add more than half to the stream.
 // Tile limits of the row-per-lane layout: window slots per class (the first 256 are the tile's own rows, slot
-// W - 1 stays empty: the padding entries' target) and rows per tile -- 256 where that still leaves every CU several tiles, fewer on small matrices.
+// W - 1 stays empty: the padding entries' target) and rows per tile -- 256 where that still gives every CU a tile, fewer on small matrices.
 struct sell_params { int lw, ecap, row_cap; };
 sell_params sell_plan_params(int n)
 {
     sell_params p;
     p.lw = 10;
     p.ecap = (1 << p.lw) - KMCF_BLOCK - 1;          // columns outside the tile's own rows
+    // (a rank's share of the 40 nm matrix in an 8-rank group, 225 k rows: 7.0 us with 256-row tiles, 10.8 with
+    // 128, 13.8 with 64 -- large tiles win as long as every CU gets one)
     int row_cap = KMCF_BLOCK;
-    while (row_cap > 64 && n / row_cap < 2048) row_cap /= 2;
+    while (row_cap > 64 && n / row_cap < 256) row_cap /= 2;
     p.row_cap = std::min(KMCF_BLOCK, std::max(64, env_int("KMCF_SPMV_SELL_ROWS", row_cap) / 64 * 64));
     return p;
 }

@@ -99,3 +99,66 @@ def test_dictionary_size_limit(km, torch, monkeypatch, ndistinct, coded):
     np.testing.assert_allclose(Ap.cpu().numpy(), M @ x, rtol=1e-13, atol=1e-13)
     mat.close()
     comm.close()
+
+
+@pytest.mark.parametrize("sort", [1, 0])
+@pytest.mark.parametrize("nvals", [1, 2, 3])
+def test_row_per_lane_kernel_ragged_rows(km, torch, monkeypatch, sort, nvals):
+    """spmv_sell_kernel on rows of 0 ... 64 off-diagonal entries (empty rows, rows without a diagonal, a tile cut by
+    its window limit), 1-3 dictionary values, with the rows sorted into the internal order (lane t owns row r0 + t)
+    and with KMCF_SPMV_SELL_SORT=0 (lane rows read from a table); bit-identical to each other and to the plain
+    window kernel's products added in column order."""
+    import scipy.sparse as sp
+    if not CODED_ON or os.environ.get("KMCF_SPMV_SELL", "1") == "0":
+        pytest.skip("row-per-lane kernel switched off")
+    S = km.solvers
+    monkeypatch.setenv("KMCF_SPMV_KIND", "2")
+    monkeypatch.setenv("KMCF_SPMV_SELL_SORT", str(sort))
+    rng = np.random.default_rng(17)
+    n = 6000
+    vals = np.array([-1.0, -0.125, -3.0])[:nvals]
+    rows, cols, data = [], [], []
+    for i in range(n):
+        k = int(rng.integers(0, 65)) if i % 7 else 0                 # every 7th row: diagonal only (or nothing)
+        lo, hi = max(0, i - 400), min(n, i + 400)
+        if i % 500 < 40:                                             # stretches with far-away columns: window-limited tiles
+            cand = rng.choice(n, size=min(k, n - 1), replace=False)
+        else:
+            cand = rng.choice(np.arange(lo, hi), size=min(k, hi - lo - 1), replace=False)
+        cand = cand[cand != i]
+        rows += [i] * len(cand)
+        cols += list(cand)
+        data += list(rng.choice(vals, len(cand)))
+        if i % 11:                                                   # some rows have no diagonal entry
+            rows.append(i); cols.append(i); data.append(5.0 + rng.random())
+    M = sp.csr_matrix((data, (rows, cols)), shape=(n, n))
+    M.sum_duplicates()
+    M.sort_indices()
+    comm = S.KMC_comm(n, n, n, n)
+    comm.connect()
+    mat = S.Distributed_matrix(comm, n, [n], [0], M.indices, M.indptr, M.data)
+    info = mat.info()
+    assert info["spmv_kind"] == 2 and info["spmv_coded"] == 2, info
+    x = rng.standard_normal(n)
+    p = torch.as_tensor(x, device="cuda")
+    Ap = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+    mat.spmv(p, Ap)
+    y = Ap.cpu().numpy()
+    want = M @ x
+    bound = abs(M) @ np.abs(x)
+    assert np.all(np.abs(y - want) <= 1e-14 * bound + 1e-300)
+    np.testing.assert_array_equal(mat.get_values(), M.data)
+    # the dictionary order of accumulation: off-diagonals in column order, the diagonal last
+    ref = np.zeros(n)
+    for i in range(n):
+        s = 0.0
+        dg = 0.0
+        for j in range(M.indptr[i], M.indptr[i + 1]):
+            if M.indices[j] == i:
+                dg = M.data[j]
+            else:
+                s += M.data[j] * x[M.indices[j]]
+        ref[i] = s + dg * x[i]
+    np.testing.assert_array_equal(y, ref)
+    mat.close()
+    comm.close()

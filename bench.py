@@ -140,10 +140,17 @@ def main():
         for name, use in (("rccl", 0), ("p2p", 1)):
             try:
                 comm.select_transport(use)
-                t_trial, _ = timed_solve(min(args.steps, 20), 3)
-                transports[name] = {"trial_ms_per_step": round(t_trial * 1e3 / min(args.steps, 20), 5)}
+                t_trial, st_trial = timed_solve(min(args.steps, 20), 3)
+                transports[name] = {"trial_ms_per_step": round(t_trial * 1e3 / min(args.steps, 20), 5),
+                                    "trial_rz": st_trial["rz"]}
             except km.lib.KmcfError as e:
                 transports[name] = {"error": str(e)[:200]}
+        # the two transports run the same recurrence (the dots differ only in the order the ranks' partial sums are
+        # added): a residual that disagrees beyond rounding means the peer-to-peer exchange delivered wrong data
+        if all("trial_rz" in v for v in transports.values()) and len(transports) == 2:
+            a, b = transports["rccl"]["trial_rz"], transports["p2p"]["trial_rz"]
+            if not (abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1e-300)):
+                transports["p2p"] = {"error": "residual after the trial solve differs from the RCCL transport's: %r vs %r" % (b, a)}
         ok = {k: v["trial_ms_per_step"] for k, v in transports.items() if "trial_ms_per_step" in v}
         pick = torch.tensor([1 if ("p2p" in ok and ok["p2p"] <= ok.get("rccl", 1e30)) else 0])
         dist.broadcast(pick, src=0)

@@ -6,7 +6,8 @@ table and the corrected HBM traffic of the SpMV kernel.
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reports exactly
 half of the bytes of a coalesced streaming read -> doubled.  The factor is calibrated in this very run on
-kernels with a known byte count (cg_p_kernel reads 3 vectors, cg_xr_kernel reads 5 and writes 2)."""
+kernels with a known byte count (cg_p_kernel reads 4 vectors -- r, 1/diag, p, x -- and writes 2, cg_xr_kernel reads
+3 -- Ap, r, 1/diag -- and writes 1; round 1: 3 / 5+2)."""
 import collections
 import csv
 import glob
@@ -38,9 +39,9 @@ def main():
         return [r for r in rows if r[0].startswith(name)]
     p = get("cg_p_kernel")[0]
     xr = get("cg_xr_kernel")[0]
-    cal_p = p[2] * 1024 / (3 * vec)
-    cal_xr = xr[2] * 1024 / (5 * vec)
-    cal_w = xr[3] * 1024 / (2 * vec)
+    cal_p = p[2] * 1024 / (4 * vec)
+    cal_xr = xr[2] * 1024 / (3 * vec)
+    cal_w = xr[3] * 1024 / (1 * vec)
     # every SpMV kernel of the run (the bench line times the plan's kernel and, re-planned, the CSR stream kernel)
     kernels = []
     for sp in get("spmv_"):

@@ -373,12 +373,15 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 //     already multiplied (xs[c][slot] = dict[c] * x[wcol[slot]]), and an entry IS the LDS byte offset of its
 //     product: ((code << LW) | slot) << 3.  Per entry: one 16-bit extract, one ds_read_b64, one add -- the
 //     same products, added in the row's column order;
-//   * one row per lane, rows of a tile (<= 256 rows, one shared window) sorted by length, so a wave's lanes run
-//     equally long; the wave's stream is [step][lane][4 entries], padded to its longest row with the offset of
-//     a slot that holds 0.0.  A step is one coalesced 8-byte load per lane straight into registers: the stream
-//     never touches LDS, the trip count is a scalar, nothing in the loop is divergent.  The sort is part of the
-//     matrix's internal row order (kmcf_sell_refine_order), so lane t of a tile owns row r0 + t and x, the
-//     diagonal and y are contiguous (IDENT); a matrix ordered otherwise reads its lane rows from lrow;
+//   * one row per lane, rows of a tile (<= 256 rows, one shared window) dealt to waves by length (sell_lane_order),
+//     so a wave's lanes run about equally long; the wave's stream is [step][lane][4 entries], padded to its
+//     longest row with the offset of a slot that holds 0.0.  A step is one coalesced 8-byte load per lane straight
+//     into registers: the stream never touches LDS, the trip count is a scalar, nothing in the loop is divergent.
+//     The lane order is part of the matrix's internal row order (kmcf_sell_refine_order), so lane t of a tile owns
+//     row r0 + t and x, the diagonal and y are contiguous (IDENT); a matrix ordered otherwise reads its lane
+//     rows from lrow;
+//   * window slots 0 .. 255 are the tile's own rows (staged from the row's x load), the others the columns outside
+//     the tile, gathered through the window map wcol;
 //   * the register a step frees receives the same step of the next tile at once: one register set holds the
 //     stream of two tiles in flight (with a second set: 106 VGPRs, 4 blocks per CU, 41.9 us; with one: 81,
 //     5 blocks, 37.6 us on the 40 nm K matrix).

@@ -515,7 +515,8 @@ static int k_assemble_async(kmcf_kstate *k, const int *d_site_element, const int
         KMCF_TRY(kmcf_matrix_set_dictionary(m, dict, 2));
         unsigned short *code_idx = m->coded ? m->d_idx16 : nullptr;
         double *code_diag = m->coded ? m->d_diagv : nullptr;
-        const bool tiled = m->coded && m->spmv_kind == 2 && m->spmv_u == 8 && m->tiles_for_coded &&
+        // (the tiles cover the short rows only: a matrix with long rows -- never K in practice -- is assembled row-wise)
+        const bool tiled = m->coded && m->spmv_kind == 2 && m->spmv_u == 8 && m->tiles_for_coded && m->n_short == m->n_loc &&
                            !(getenv("KMCF_ASM_TILED") && atoi(getenv("KMCF_ASM_TILED")) == 0);
         if (tiled) {
             const int tgrid = std::min(m->n_tiles, 8 * 256 * 4);

@@ -1009,7 +1009,7 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     KMCF_HIP(hipMemcpy(m->d_diag_pos, m->h_diag_pos.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_dict), 64 * sizeof(double)));
     KMCF_HIP(hipMemset(m->d_dict, 0, 64 * sizeof(double)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_diagv), (size_t)n * sizeof(double)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_diagv), (size_t)std::max(m->n_loc, 1) * sizeof(double)));   // (every row: the row-wise K assembly writes all of them)
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_code_fail), sizeof(int)));
     m->coded = false;
     *ok = true;

@@ -182,6 +182,7 @@ struct kmcf_matrix {
     int spmv_grid = 0;                 // interior pass grid (= number of pAp partials it writes)
     int spmv_grid_b = 0;               // boundary pass grid
     int spmv_lpr = 16;                 // lanes per row (vec kernel)
+    bool stream_nt = false;            // the f64-value kernels mark their matrix loads nontemporal (matrix larger than the caches)
     int spmv_kind = 0;                 // 0: vec<LPR>, 1: stream (nnz-chunked, LDS row reduction), 2: window
     // window kernel (kind 2): tiles of whole rows whose distinct columns (<= spmv_wmax) are staged in LDS
     int n_tiles = 0;

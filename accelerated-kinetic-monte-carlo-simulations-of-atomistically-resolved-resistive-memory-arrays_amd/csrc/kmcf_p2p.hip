@@ -406,8 +406,12 @@ int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
     ++w->seq_gather;
     const size_t half_off = w->stage_off + (w->seq_gather & 1) * w->stage_half;
     const size_t my_words = (size_t)counts[rank] * wpe;
-    const int g1 = (int)std::min<size_t>(std::max<size_t>(my_words / (KMCF_BLOCK * 4), 1), 256);
-    const int g2 = (int)std::min<size_t>(std::max<size_t>(woff[P] / (KMCF_BLOCK * 4), 1), 512);
+    // Few blocks: every block of these kernels spins on flags, and ranks that share one GPU (the in-process test
+    // groups, several processes on one device) must never fill it with waiting blocks while the kernel that would
+    // release them cannot be scheduled (seen once: 4 ranks x 512 waiting blocks = every block slot of the chip).
+    // The link, not the block count, bounds a gather anyway.
+    const int g1 = (int)std::min<size_t>(std::max<size_t>(my_words / (KMCF_BLOCK * 4), 1), 48);
+    const int g2 = (int)std::min<size_t>(std::max<size_t>(woff[P] / (KMCF_BLOCK * 4), 1), 48);
     unsigned int *buf32 = static_cast<unsigned int *>(d_buf);
     p2p_gather_stage_kernel<<<g1, KMCF_BLOCK, 0, c->stream>>>(w->d_peer, P, rank, buf32 + woff[rank],
                                                               reinterpret_cast<unsigned int *>(w->win + half_off) + woff[rank], my_words,

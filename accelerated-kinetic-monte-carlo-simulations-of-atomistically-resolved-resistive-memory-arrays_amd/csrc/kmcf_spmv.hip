@@ -55,8 +55,20 @@ __device__ __forceinline__ double block_sum_256(double v, double *lds4)
     return t;
 }
 
+// Matrix data a kernel reads once per launch.  Marked nontemporal (streaming: do not keep it in the caches) only
+// where the matrix is larger than the caches anyway: measured on the 40 nm K matrix (round 2), 534 MB of CSR
+// stream 141 us nontemporal / 148 us plain, 481 MB of window format 129 / 133 -- but the 2 B/nnz formats, which
+// FIT the 256 MiB Infinity Cache together with the CG's vectors, 57 / 42 us (coded window kernel) and
+// 33.7 / 25.0 us (row-per-lane kernel): the hint evicts what the next iteration would have found in the cache.
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 // ------------------------------------------------------------------ stream kernel
-template <int U, int LPR2, bool DOT, bool SKIP_BOUNDARY>
+template <int U, int LPR2, bool DOT, bool SKIP_BOUNDARY, bool NT>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
     int n_chunks, const int *__restrict__ chunk_row, const int *__restrict__ row_ptr,
     const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
@@ -84,8 +96,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
             const int i = u * KMCF_BLOCK + tid;
             const bool in = i < cnt;
             // streamed once: nontemporal loads keep the vector L1 for the x lines
-            v[u] = in ? __builtin_nontemporal_load(val + base + i) : 0.0;
-            ci[u] = in ? __builtin_nontemporal_load(col + base + i) : 0;
+            v[u] = in ? stream_load<NT>(val + base + i) : 0.0;
+            ci[u] = in ? stream_load<NT>(col + base + i) : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_stream_kernel(
 // lanes read neighbouring addresses, so the texture path merges them), and the per-entry gather happens in
 // LDS through 16-bit window slots instead of one L1 tag lookup per lane (PMC: 45.6 M TCP accesses per launch
 // for the stream kernel, most of them single-lane gathers).  Values keep their CSR order and stay f64.
-template <int U, int WQ, int LPR2, bool DOT, bool SKIP_BOUNDARY>
+template <int U, int WQ, int LPR2, bool DOT, bool SKIP_BOUNDARY, bool NT>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
     int n_tiles, const int2 *__restrict__ tile, const int *__restrict__ row_ptr, const int *__restrict__ wcol,
     const unsigned short *__restrict__ idx16, const double *__restrict__ val, const double *__restrict__ x,
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
             const int w = q * KMCF_BLOCK + tid;
-            wc[q] = w < W ? __builtin_nontemporal_load(wcol + w0 + w) : -1;
+            wc[q] = w < W ? stream_load<NT>(wcol + w0 + w) : -1;
         }
         double v[U];
         unsigned short ci[U];
@@ -162,8 +174,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_window_kernel(
         for (int u = 0; u < U; ++u) {
             const int i = u * KMCF_BLOCK + tid;
             const bool in = i < cnt;
-            v[u] = in ? __builtin_nontemporal_load(val + base + i) : 0.0;
-            ci[u] = in ? __builtin_nontemporal_load(idx16 + base + i) : (unsigned short)0;
+            v[u] = in ? stream_load<NT>(val + base + i) : 0.0;
+            ci[u] = in ? stream_load<NT>(idx16 + base + i) : (unsigned short)0;
         }
 #pragma unroll
         for (int q = 0; q < WQ; ++q)
@@ -262,10 +274,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
         int wc0[WQ], wc1[WQ];
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
-            wc0[q] = __builtin_nontemporal_load(wcol + d0.z + min(q * KMCF_BLOCK + tid, max(d0.w - 1, 0)));
-            wc1[q] = __builtin_nontemporal_load(wcol + d1.z + min(q * KMCF_BLOCK + tid, max(d1.w - 1, 0)));
+            wc0[q] = stream_load<false>(wcol + d0.z + min(q * KMCF_BLOCK + tid, max(d0.w - 1, 0)));
+            wc1[q] = stream_load<false>(wcol + d1.z + min(q * KMCF_BLOCK + tid, max(d1.w - 1, 0)));
         }
-        pack_t pk = __builtin_nontemporal_load(reinterpret_cast<const pack_t *>(idx16 + (b0 & ~(U - 1))) + tid);
+        pack_t pk = stream_load<false>(reinterpret_cast<const pack_t *>(idx16 + (b0 & ~(U - 1))) + tid);
         int nb, ne;
         double nxrow, ndg, xr[WQ];
         {
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 #pragma unroll
             for (int q = 0; q < WQ; ++q) xw[buf][q * KMCF_BLOCK + tid] = xr[q];
             // ---- C(k+1): everything tile k+1 needs is requested now and lands while tile k is reduced
-            pk = __builtin_nontemporal_load(reinterpret_cast<const pack_t *>(idx16 + (b1 & ~(U - 1))) + tid);
+            pk = stream_load<false>(reinterpret_cast<const pack_t *>(idx16 + (b1 & ~(U - 1))) + tid);
             {
                 const int rc = d1.x + min(tid / LPR2, d1.y - 1);
                 nb = row_ptr[rc]; ne = row_ptr[rc + 1]; nxrow = x[rc]; ndg = diagv[rc];
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 #pragma unroll
             for (int q = 0; q < WQ; ++q) {
                 wc0[q] = wc1[q];
-                wc1[q] = __builtin_nontemporal_load(wcol + d2.z + min(q * KMCF_BLOCK + tid, max(d2.w - 1, 0)));
+                wc1[q] = stream_load<false>(wcol + d2.z + min(q * KMCF_BLOCK + tid, max(d2.w - 1, 0)));
             }
             d0 = d1; b0 = b1;
             d1 = d2; b1 = b2;
@@ -427,8 +439,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
         // stage B: window map (and lane rows) of a tile
         auto load_b = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
 #pragma unroll
-            for (int q = 0; q < WQ; ++q) wc[q] = __builtin_nontemporal_load(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)));
-            if (!IDENT) lr = __builtin_nontemporal_load(lrow + (size_t)c * KMCF_BLOCK + tid);
+            for (int q = 0; q < WQ; ++q) wc[q] = wcol[d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0))];
+            if (!IDENT) lr = lrow[(size_t)c * KMCF_BLOCK + tid];
         };
         // the same with (wave-scope, relaxed) atomic loads, which stay where they are written and cost nothing
         // extra: the prologue must issue in the loop body's order (B before C) or the wait counts derived for the
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             const sell_pair *sp = stream + s0.x + lane;
             const int last = max(s0.y - 1, 0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) pk[q] = __builtin_nontemporal_load(sp + min(q, last) * 64);
+            for (int q = 0; q < NQ; ++q) pk[q] = sp[min(q, last) * 64];
         }
         // wu / lu: window map and lane rows of tile k+1 (loaded an iteration ago); wl / ll: receive tile k+2's.
         // B is issued before C so that waiting for tile k+1's map next iteration leaves this iteration's later
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
                     const double a3 = *reinterpret_cast<const double *>(base + (e.y >> 16));
                     s += a0; s += a1; s += a2; s += a3;
                 }
-                pk[q] = __builtin_nontemporal_load(spn + min(q, lastn) * 64);
+                pk[q] = spn[min(q, lastn) * 64];
             }
             if (cur.valid) {
                 s += cur.dg * cur.xrow;
@@ -713,13 +725,16 @@ void launch_stream(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     const int chk = skip_if_done ? 1 : 0;
     const int grid = kmcf_interior_grid(m);
     const bool skipb = (m->n_halo > 0);
-    if (with_dot) {
-        if (skipb) spmv_stream_kernel<U, LPR2, true, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, m->d_part_a));
-        else spmv_stream_kernel<U, LPR2, true, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, m->d_part_a));
-    } else {
-        if (skipb) spmv_stream_kernel<U, LPR2, false, true><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, nullptr));
-        else spmv_stream_kernel<U, LPR2, false, false><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, nullptr));
+#define KMCF_STREAM_LAUNCH(NT)                                                                                                       \
+    if (with_dot) {                                                                                                                  \
+        if (skipb) spmv_stream_kernel<U, LPR2, true, true, NT><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, m->d_part_a)); \
+        else spmv_stream_kernel<U, LPR2, true, false, NT><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, m->d_part_a));  \
+    } else {                                                                                                                         \
+        if (skipb) spmv_stream_kernel<U, LPR2, false, true, NT><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(m->d_is_boundary, nullptr)); \
+        else spmv_stream_kernel<U, LPR2, false, false, NT><<<grid, KMCF_BLOCK, 0, st>>>(KMCF_STREAM_ARGS(nullptr, nullptr));      \
     }
+    if (m->stream_nt) { KMCF_STREAM_LAUNCH(true) } else { KMCF_STREAM_LAUNCH(false) }
+#undef KMCF_STREAM_LAUNCH
 }
 
 #define KMCF_WINDOW_ARGS(isb, part) \
@@ -747,13 +762,16 @@ int window_dispatch(kmcf_matrix *m, int which, bool launch, bool with_dot, bool 
     const int grid = launch ? kmcf_interior_grid(m) : 0;
     int pc = 0;
     if (which == 0) {
-        if (with_dot) {
-            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, true, true>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
-            else run_or_query(spmv_window_kernel<U, WQ, 4, true, false>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
-        } else {
-            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, false, true>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
-            else run_or_query(spmv_window_kernel<U, WQ, 4, false, false>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));
+#define KMCF_WINDOW_LAUNCH(NT)                                                                                                            \
+        if (with_dot) {                                                                                                                   \
+            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, true, true, NT>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));    \
+            else run_or_query(spmv_window_kernel<U, WQ, 4, true, false, NT>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));          \
+        } else {                                                                                                                          \
+            if (skipb) run_or_query(spmv_window_kernel<U, WQ, 4, false, true, NT>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));   \
+            else run_or_query(spmv_window_kernel<U, WQ, 4, false, false, NT>, launch, &pc, grid, st, KMCF_WINDOW_ARGS(isb, part));         \
         }
+        if (m->stream_nt) { KMCF_WINDOW_LAUNCH(true) } else { KMCF_WINDOW_LAUNCH(false) }
+#undef KMCF_WINDOW_LAUNCH
     } else {
         if (with_dot) {
             if (skipb) run_or_query(spmv_wcode_kernel<U, WQ, true, true>, launch, &pc, grid, st, KMCF_WCODE_ARGS(isb, part));
@@ -1250,6 +1268,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void encode_values_kernel(int n, const 
 
 int kmcf_spmv_plan(kmcf_matrix *m)
 {
+    // f64-value kernels: nontemporal matrix loads once the CSR stream alone is beyond what the caches can keep
+    // between two launches (stream_load; KMCF_SPMV_NT = 0 / 1 overrides)
+    m->stream_nt = 12.0 * (double)m->nnz > 192e6;
+    if (const char *e = getenv("KMCF_SPMV_NT")) m->stream_nt = atoi(e) != 0;
     // vec kernel: lanes per row from the mean row length (K rows hold 4..53 entries, mean 25.8)
     const double mean = m->n_short > 0 ? double(m->h_row_ptr[m->n_short]) / m->n_short : 0.0;
     int lpr = 4;

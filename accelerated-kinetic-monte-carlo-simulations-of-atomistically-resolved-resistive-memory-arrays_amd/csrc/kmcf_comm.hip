@@ -449,8 +449,11 @@ extern "C" int kmcf_comm_select_transport(kmcf_comm *c, int use_p2p)
     if (c->nranks == 1) return KMCF_OK;
     if (use_p2p) {
         KMCF_CHECK(c->p2p != nullptr, KMCF_ERR_STATE, "kmcf_comm_select_transport: the peer-to-peer transport was not set up");
-        KMCF_TRY(kmcf_p2p_check(c));
         c->p2p_active = true;
+        if (kmcf_p2p_check(c) != KMCF_OK) {          // it has failed before: stays off
+            c->p2p_active = false;
+            return KMCF_ERR_COMM;
+        }
     } else {
         KMCF_CHECK(c->group || c->nccl_red, KMCF_ERR_STATE, "kmcf_comm_select_transport: no other transport is connected");
         c->p2p_active = false;

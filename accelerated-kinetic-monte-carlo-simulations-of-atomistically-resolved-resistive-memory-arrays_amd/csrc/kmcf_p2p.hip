@@ -358,6 +358,9 @@ extern "C" int kmcf_comm_p2p_import(kmcf_comm *c, const void *h_handles)
 int kmcf_p2p_check(kmcf_comm *c)
 {
     if (!c || !c->p2p || *c->p2p->h_err == 0) return KMCF_OK;
+    // (a transport that failed and was switched off -- bench.py's trial, KMCF_TRANSPORT=auto -- must not fail the calls
+    // that now run over RCCL; kmcf_comm_select_transport refuses to switch it on again)
+    if (!c->p2p_active) return KMCF_OK;
     static const char *what[] = {"", "all-reduce", "halo exchange", "all-gather (data)", "all-gather (acknowledgement)"};
     const int code = *c->p2p->h_err;
     kmcf_set_error("p2p transport: rank %d timed out in %s -- a peer did not arrive within the bound (KMCF_P2P_TIMEOUT_MS)", c->rank,

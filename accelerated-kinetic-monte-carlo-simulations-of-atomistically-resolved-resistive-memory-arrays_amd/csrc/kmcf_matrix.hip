@@ -431,6 +431,18 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
     return KMCF_OK;
 }
 
+extern "C" int kmcf_matrix_row_order(const kmcf_matrix *m, int *h_perm, int *n_short, int *h_tile_end, int *n_tiles)
+{
+    KMCF_CHECK(m, KMCF_ERR_ARG, "kmcf_matrix_row_order: null matrix");
+    if (h_perm)
+        for (int i = 0; i < m->n_loc; ++i) h_perm[i] = m->h_perm.empty() ? i : m->h_perm[i];
+    if (n_short) *n_short = m->n_short;
+    if (n_tiles) *n_tiles = (int)m->h_sell_cuts.size();
+    if (h_tile_end)
+        for (size_t t = 0; t < m->h_sell_cuts.size(); ++t) h_tile_end[t] = m->h_sell_cuts[t];
+    return KMCF_OK;
+}
+
 extern "C" int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info)
 {
     KMCF_CHECK(m && info, KMCF_ERR_ARG, "kmcf_matrix_info: null argument");

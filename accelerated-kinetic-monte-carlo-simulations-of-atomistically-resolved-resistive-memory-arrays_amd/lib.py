@@ -72,6 +72,7 @@ SIGNATURES = {
     "kmcf_matrix_create_split_sparse": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _DP, C.c_int, _IP, _IP, _IP, _IP,
                                                   _IP, _DP, C.POINTER(_P)]),
     "kmcf_matrix_info": (C.c_int, [_P, C.POINTER(MatrixInfo)]),
+    "kmcf_matrix_row_order": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
     "kmcf_matrix_neighbour": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _IP, _IP]),
     "kmcf_matrix_set_values": (C.c_int, [_P, _DP]),
     "kmcf_matrix_get_values": (C.c_int, [_P, _DP]),

@@ -555,6 +555,18 @@ class Distributed_matrix:
         _L.check(self.lib.kmcf_matrix_info(self.handle, C.byref(inf)), "kmcf_matrix_info")
         return {k: getattr(inf, k) for k, _ in inf._fields_}
 
+    def row_order(self):
+        """kmcf_matrix_row_order: (perm, n_short, tile_ends) of the internal row order."""
+        n = self.info()["rows_this_rank"]
+        perm = np.zeros(max(n, 1), np.int32)
+        ns, nt = C.c_int(0), C.c_int(0)
+        _L.check(self.lib.kmcf_matrix_row_order(self.handle, perm.ctypes.data_as(C.POINTER(C.c_int)), C.byref(ns), None,
+                                                C.byref(nt)), "kmcf_matrix_row_order")
+        ends = np.zeros(max(nt.value, 1), np.int32)
+        _L.check(self.lib.kmcf_matrix_row_order(self.handle, None, None, ends.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nt)),
+                 "kmcf_matrix_row_order")
+        return perm[:n], ns.value, ends[:nt.value]
+
     def neighbours(self):
         """[(rank, nnz, cols_per_neighbour, rows_per_neighbour), ...] starting with self."""
         out = []

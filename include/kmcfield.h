@@ -142,6 +142,13 @@ int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info);
 int kmcf_matrix_neighbour(const kmcf_matrix *m, int k, int *neighbour_rank, int *nnz_block,
                           int *ncols, int *h_cols, int *nrows, int *h_rows);
 
+/* Internal row order for inspection (no reference counterpart: the reference keeps the caller's order).
+ * h_perm[i] = caller's local row stored as internal row i (rows_this_rank entries; NULL: skip).  The rows longer
+ * than KMCF_LONG_ROW come last; *n_short = number of rows before them.  h_tile_end: end row (exclusive, internal
+ * order) of every tile of the row-per-lane SpMV layout, *n_tiles of them (pass NULL to query the count; 0 when
+ * the order was not refined for that layout). */
+int kmcf_matrix_row_order(const kmcf_matrix *m, int *h_perm, int *n_short, int *h_tile_end, int *n_tiles);
+
 /* Overwrite the values (same order as the CSR given at creation). */
 int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val);
 /* Copy the values back (creation order). */

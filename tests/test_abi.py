@@ -114,3 +114,40 @@ def test_synthetic_crossbar_generator_is_deterministic(km):
     assert np.all(xx[:576] == xx.min()) and np.all(xx[-576:] == xx.max())
     mid_y = a["xyz"][576:-576, 1]
     assert np.all(np.diff(mid_y) >= 0)                           # "bwmin": sorted along y
+
+
+@pytest.mark.parametrize("long_row", [384, 45])
+def test_internal_row_order_is_refined_for_the_row_per_lane_layout(km, oracle, ref5, monkeypatch, long_row):
+    """kmcf_matrix_build on the host (no GPU): the internal row order is a permutation, rows beyond KMCF_LONG_ROW come
+    last, and inside every tile of the row-per-lane SpMV layout (<= 256 rows, <= 767 columns outside the tile) the
+    rows are dealt to wavefronts by length (the 64 longest first, ...), original order inside a wavefront."""
+    S = km.solvers
+    monkeypatch.setenv("KMCF_LONG_ROW", str(long_row))
+    ks = ref5["ks"]
+    h = _host_comm(km, 1, 0)
+    m = S.Distributed_matrix(_Comm(h), ks.n, [ks.n], [0], ks.col, ks.row_ptr, None)
+    perm, n_short, ends = m.row_order()
+    n = ks.n
+    assert sorted(perm.tolist()) == list(range(n))
+    length = np.diff(ks.row_ptr)
+    is_long = length[perm] > long_row
+    assert n_short == n - int(is_long.sum()) and not is_long[:n_short].any() and is_long[n_short:].all()
+    assert len(ends) > 0 and ends[-1] == n_short and np.all(np.diff(np.r_[0, ends]) > 0)
+    rp, col = ks.row_ptr, ks.col
+    offdiag = np.array([np.count_nonzero(col[rp[r]:rp[r + 1]] != r) for r in range(n)])
+    start = 0
+    for e in ends:
+        rows = perm[start:e]
+        assert len(rows) <= 256
+        inside = set(rows.tolist())
+        outside = {int(c) for r in rows for c in col[rp[r]:rp[r + 1]] if int(c) not in inside}
+        assert len(outside) <= 767
+        lens = offdiag[rows]
+        for w in range(0, len(rows), 64):                       # wave w holds no row shorter than any row of wave w + 1
+            if w + 64 < len(rows):
+                assert lens[w:w + 64].min() >= lens[w + 64:w + 128].max()
+        start = int(e)
+    # the halo protocol and the exported pattern are in the caller's order, whatever the internal one
+    assert m.info()["rows_this_rank"] == n
+    m.close()
+    km.lib.load().kmcf_comm_destroy(h)

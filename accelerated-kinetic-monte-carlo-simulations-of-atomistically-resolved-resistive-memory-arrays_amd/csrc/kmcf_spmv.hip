@@ -400,6 +400,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 // Stages per iteration k as in the kernel above: D(k) stage + reduce (+ stream of k+1), C(k+1) gathers and row
 // data, B(k+2) window map (+ lane rows), A(k+3) descriptors.
 typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries
+#ifdef KMCF_SELL_NT_LAB
+#define KMCF_SELL_LD(p) __builtin_nontemporal_load(p)
+#else
+#define KMCF_SELL_LD(p) (*(p))
+#endif
 
 template <int WQ>
 struct sell_regs {
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             const sell_pair *sp = stream + s0.x + lane;
             const int last = max(s0.y - 1, 0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) pk[q] = sp[min(q, last) * 64];
+            for (int q = 0; q < NQ; ++q) pk[q] = KMCF_SELL_LD(sp + min(q, last) * 64);
         }
         // wu / lu: window map and lane rows of tile k+1 (loaded an iteration ago); wl / ll: receive tile k+2's.
         // B is issued before C so that waiting for tile k+1's map next iteration leaves this iteration's later
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
                     const double a3 = *reinterpret_cast<const double *>(base + (e.y >> 16));
                     s += a0; s += a1; s += a2; s += a3;
                 }
-                pk[q] = spn[min(q, lastn) * 64];
+                pk[q] = KMCF_SELL_LD(spn + min(q, lastn) * 64);
             }
             if (cur.valid) {
                 s += cur.dg * cur.xrow;

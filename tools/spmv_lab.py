@@ -25,7 +25,7 @@ def main():
     specs = args or ["KIND=0,LPR=16", "KIND=1,U=8,LPR2=4"]
     S = km.solvers
     order = os.environ.get("LAB_ORDER", "bwmin")
-    d = km.structure.synth_crossbar_40nm(order=order) if workload == "40nm" else km.structure.synth_small(tiles=2, order=order)
+    d = km.structure.synth_crossbar_40nm(order=order, tiles=int(os.environ.get("LAB_TILES", "8"))) if workload == "40nm" else km.structure.synth_small(tiles=2, order=order)
     print("order", order)
     NL = d["N_contact"]
     comm = S.KMC_comm(d["N"] - 2 * NL, d["N"] + 1, d["N"], d["N"])

@@ -400,6 +400,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 // Stages per iteration k as in the kernel above: D(k) stage + reduce (+ stream of k+1), C(k+1) gathers and row
 // data, B(k+2) window map (+ lane rows), A(k+3) descriptors.
 typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries
+// the stream is loaded with plain (cacheable) loads -- see stream_load above; -DKMCF_SELL_NT_LAB is the
+// nontemporal variant of the measurements in tools/lab/big_lab.sh
 #ifdef KMCF_SELL_NT_LAB
 #define KMCF_SELL_LD(p) __builtin_nontemporal_load(p)
 #else

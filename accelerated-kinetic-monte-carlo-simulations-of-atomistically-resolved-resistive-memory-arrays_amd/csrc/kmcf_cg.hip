@@ -107,10 +107,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_finalize_kernel(part_ref p0, in
 template <bool PRECOND>
 __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restrict__ p, const double *__restrict__ r,
                                                           const double *__restrict__ dinv, part_ref prz, part_ref pbb,
-                                                          kmcf_scalars *__restrict__ S, int parity, int first,
+                                                          kmcf_scalars *__restrict__ S, int k, int first,
                                                           double tol2, int check_tol, double *__restrict__ x)
 {
     __shared__ double lds4[4];
+    const int parity = k & 1;
     // Everything this block needs is requested before anything is waited for (scalars, the partial sums of the
     // previous kernel, the block's first elements): a block lives for one or two elements per lane, so a chain of
     // dependent loads in front of its stream would be most of its life.
@@ -118,7 +119,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
     const double2 *r2 = reinterpret_cast<const double2 *>(r), *d2 = reinterpret_cast<const double2 *>(dinv);
     double2 *p2 = reinterpret_cast<double2 *>(p);
     const int i0 = blockIdx.x * KMCF_BLOCK + threadIdx.x;
-    const int done = S->done;
+    // stopped by an EARLIER launch?  (S->done itself is written by block 0 of this very launch when the stopping rule
+    // fires: a block scheduled late would see it, return here and skip its share of the pending x update below)
+    const int stop_k = S->stop_k;
+    const bool done = stop_k != 0 && stop_k != k;
     const double rz_prev = S->rz[parity ^ 1], bb_saved = S->bb;
     double2 *x2 = reinterpret_cast<double2 *>(x);
     const int pending = S->x_pending;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_p_kernel(int n, double *__restr
         S->rz_last = rz_new;
         if (first) S->bb = bb;
         if (go) { S->rz[parity] = rz_new; S->iters += 1; }
-        else S->done = 1;
+        else { S->stop_k = k; S->done = 1; }
     }
     if (!go) {
         // the last iteration's x += alpha p, then nothing more (later kernels see S->done)
@@ -279,13 +283,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_tail_kernel(part_ref prz, kmcf_
     if (threadIdx.x == 0) S->rz_last = t;
 }
 
-int vec_grid(int n)
-{
-    int64_t g = ((int64_t)n + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
-    if (g < 1) g = 1;
-    if (g > KMCF_MAX_PARTIALS) g = KMCF_MAX_PARTIALS;    // 8 blocks per CU; one partial per block
-    return (int)g;
-}
+int vec_grid(int n) { return kmcf_vec_grid(n); }
 
 // Reads back the scalars of the solve enqueued last (after ONE stream synchronisation) and fills `stats`.
 int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *stats)
@@ -356,7 +354,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
         for (int i = 0; i < chunk; ++i) {
             const int k = launched + i + 1;  // reference's k
             const int parity = k & 1;
-            cg_p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_p, m->d_r, m->d_dinv, prz, pbb, S, parity,
+            cg_p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_p, m->d_r, m->d_dinv, prz, pbb, S, k,
                                                             k == 1 ? 1 : 0, tol2, check_tol, m->d_x);
             KMCF_HIP(hipGetLastError());
             KMCF_TRY(kmcf_spmv_device(m, true, true));
@@ -577,9 +575,7 @@ static int pcg_workspace_flags(kmcf_matrix *m, bool precond, double tol, int max
 {
     // classic = the reference's recurrence and operation order (default for one rank);
     // cg1r = single-reduction variant (default for multi-rank groups)
-    bool cg1r = m->comm->nranks > 1;
-    if (const char *e = getenv("KMCF_CG_VARIANT")) cg1r = (e[0] == 'c' && e[1] == 'g');
-    if (cg1r) {
+    if (kmcf_cg_single_reduction(m)) {
         if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
         return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -56,7 +57,8 @@ struct kmcf_scalars {
     int done;         // stopping rule met
     int iters;        // iterations executed
     int x_pending;    // classic loop: x += xa * p of the last iteration is still to be applied (cg_p / cg_x / cg_out)
-    int pad;
+    int stop_k;       // iteration whose loop-head kernel set `done` (0: none).  That kernel's own blocks test THIS word,
+                      // never `done`: block 0 writes `done` while other blocks of the same launch may not have started
     double xa;        // ... its step length
 };
 
@@ -256,11 +258,31 @@ struct kmcf_kstate {
 void kmcf_sell_free(kmcf_matrix *m);       // frees the row-per-lane layout (kmcf_spmv.hip)
 void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *col, std::vector<int> &perm, std::vector<int> &cuts);
 
+// grid of the CG's vector kernels (= r.z / b.b partials): 8 blocks per CU at most, one partial per block
+inline int kmcf_vec_grid(int n)
+{
+    int64_t g = ((int64_t)n + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
+    if (g < 1) g = 1;
+    if (g > KMCF_MAX_PARTIALS) g = KMCF_MAX_PARTIALS;
+    return (int)g;
+}
+
+// recurrence of a solve on this matrix: false = classic (the reference's operation order; default for one rank),
+// true = single-reduction variant (default for multi-rank groups); KMCF_CG_VARIANT=classic|cg1r overrides
+inline bool kmcf_cg_single_reduction(const kmcf_matrix *m);
+
 // grid of the interior SpMV pass = number of p.Ap partials it writes
 inline int kmcf_interior_grid(const kmcf_matrix *m)
 {
     if (m->spmv_kind == 2 && m->coded) return (m->sell_ok && m->dict_n <= 3) ? m->sell_grid : m->spmv_grid_coded;
     return m->spmv_grid;
+}
+
+inline bool kmcf_cg_single_reduction(const kmcf_matrix *m)
+{
+    bool cg1r = m->comm->nranks > 1;
+    if (const char *e = getenv("KMCF_CG_VARIANT")) cg1r = (e[0] == 'c' && e[1] == 'g');
+    return cg1r;
 }
 
 // Sub-block operator of a split matrix A = A_csr + P^T S P (the T matrix's tunnel block): S acts on the

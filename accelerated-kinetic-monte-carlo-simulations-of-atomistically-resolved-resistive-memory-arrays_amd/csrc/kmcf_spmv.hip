@@ -1493,6 +1493,45 @@ kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m)
     return q;
 }
 
+extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan, int *h_tile_first, int *h_tile_rows,
+                                    int *h_row_ptr, int *h_col, double *h_val)
+{
+    KMCF_CHECK(m, KMCF_ERR_ARG, "kmcf_matrix_sum_plan: null matrix");
+    KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_sum_plan: host-only matrix");
+    const bool sell = sell_active(m);
+    if (plan) {
+        memset(plan, 0, sizeof(*plan));
+        plan->rows = m->n_loc;
+        plan->n_short = m->n_short;
+        plan->halo_cols = m->n_halo;
+        plan->vec_grid = kmcf_vec_grid(m->n_loc);
+        plan->sell_active = sell ? 1 : 0;
+        plan->sell_ident = m->sell_ident ? 1 : 0;
+        plan->sell_grid = sell ? m->sell_grid : 0;
+        plan->sell_tiles = sell ? m->n_sell_tiles : 0;
+        plan->boundary_grid = m->n_halo > 0 && m->n_boundary_rows > 0 ? m->spmv_grid_b : 0;
+        plan->boundary_lpr = m->spmv_lpr;
+        plan->boundary_rows = m->n_boundary_rows;
+        plan->long_items = m->n_long_items;
+        plan->sub_grid = m->sub ? m->sub->grid : 0;
+        plan->cg_variant = kmcf_cg_single_reduction(m) ? 1 : 0;
+    }
+    KMCF_HIP(hipSetDevice(m->comm->device));
+    KMCF_HIP(hipStreamSynchronize(m->comm->stream));
+    if ((h_tile_first || h_tile_rows) && sell && m->n_sell_tiles > 0) {
+        std::vector<int4> t((size_t)m->n_sell_tiles);
+        KMCF_HIP(hipMemcpy(t.data(), m->d_sell_tile, t.size() * sizeof(int4), hipMemcpyDeviceToHost));
+        for (int i = 0; i < m->n_sell_tiles; ++i) {
+            if (h_tile_first) h_tile_first[i] = t[i].x;
+            if (h_tile_rows) h_tile_rows[i] = t[i].y;
+        }
+    }
+    if (h_row_ptr) memcpy(h_row_ptr, m->h_row_ptr.data(), ((size_t)m->n_loc + 1) * sizeof(int));
+    if (h_col && m->nnz) KMCF_HIP(hipMemcpy(h_col, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    if (h_val && m->nnz) KMCF_HIP(hipMemcpy(h_val, m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return KMCF_OK;
+}
+
 extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
 {
     // a rank that owns no rows (fewer rows than ranks) still takes part in the exchange; its vectors may be null

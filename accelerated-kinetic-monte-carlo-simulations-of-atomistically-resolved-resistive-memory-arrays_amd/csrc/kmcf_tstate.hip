@@ -1098,8 +1098,9 @@ extern "C" int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_elemen
                                             d_atom_virtual_potentials, t->d_scal);
     KMCF_HIP(hipGetLastError());
     KMCF_TRY(kmcf_comm_allreduce_sum(c, t->d_scal, 1));
-    double h_im = 0.0;
-    KMCF_HIP(hipMemcpyAsync(&h_im, t->d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+    // (into pinned memory that outlives this frame: the error returns below leave before the synchronisation)
+    double *h_im = reinterpret_cast<double *>(t->h_pin + 4);
+    KMCF_HIP(hipMemcpyAsync(h_im, t->d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
     if (p->solve_heating) {
         // shift (:2068-2071), forward currents and their row sums (:2086-2098), P = I_neg m (:2100-2131), copy_pdisp (:2137)
         min_kernel<<<1, KMCF_BLOCK, 0, st>>>(Na + 2, d_atom_virtual_potentials, t->d_scal + 1);
@@ -1121,7 +1122,7 @@ extern "C" int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_elemen
     }
     KMCF_HIP(hipStreamSynchronize(st));
     KMCF_TRY(kmcf_p2p_check(c));
-    if (imacro) *imacro = h_im;
+    if (imacro) *imacro = *h_im;
     if (stats) {
         float ms = 0.f;
         KMCF_HIP(hipEventElapsedTime(&ms, c->ev_a0, c->ev_a1));

@@ -24,6 +24,14 @@ class MatrixInfo(C.Structure):
                 ("spmv_window_cols", C.c_int64), ("spmv_stream_entries", C.c_int64)]
 
 
+class SumPlan(C.Structure):
+    """kmcf_sum_plan_t"""
+    _fields_ = [("rows", C.c_int), ("n_short", C.c_int), ("halo_cols", C.c_int), ("vec_grid", C.c_int),
+                ("sell_active", C.c_int), ("sell_ident", C.c_int), ("sell_grid", C.c_int), ("sell_tiles", C.c_int),
+                ("boundary_grid", C.c_int), ("boundary_lpr", C.c_int), ("boundary_rows", C.c_int),
+                ("long_items", C.c_int), ("sub_grid", C.c_int), ("cg_variant", C.c_int), ("reserved", C.c_int * 3)]
+
+
 class TStateInfo(C.Structure):
     _fields_ = [("N_atom", C.c_int), ("Nsub", C.c_int), ("rows_this_rank", C.c_int), ("nnz_neighbour", C.c_int64),
                 ("tunnel_points", C.c_int), ("tunnel_points_rank", C.c_int), ("tunnel_first", C.c_int),
@@ -73,6 +81,7 @@ SIGNATURES = {
                                                   _IP, _DP, C.POINTER(_P)]),
     "kmcf_matrix_info": (C.c_int, [_P, C.POINTER(MatrixInfo)]),
     "kmcf_matrix_row_order": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
+    "kmcf_matrix_sum_plan": (C.c_int, [_P, C.POINTER(SumPlan), _IP, _IP, _IP, _IP, _DP]),
     "kmcf_matrix_neighbour": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _IP, _IP]),
     "kmcf_matrix_set_values": (C.c_int, [_P, _DP]),
     "kmcf_matrix_get_values": (C.c_int, [_P, _DP]),

@@ -567,6 +567,28 @@ class Distributed_matrix:
                  "kmcf_matrix_row_order")
         return perm[:n], ns.value, ends[:nt.value]
 
+    def sum_plan(self, with_csr=True):
+        """kmcf_matrix_sum_plan: the integers that fix the summation order of the solver kernels, the row-per-lane
+        tiles and (with_csr) the CSR in the internal order -- what the CPU oracle needs to add in the device's order."""
+        pl = _L.SumPlan()
+        _L.check(self.lib.kmcf_matrix_sum_plan(self.handle, C.byref(pl), None, None, None, None, None), "kmcf_matrix_sum_plan")
+        out = {k: getattr(pl, k) for k, _ in pl._fields_ if k != "reserved"}
+        nt, n, nnz = max(pl.sell_tiles, 1), pl.rows, int(self.info()["nnz"])
+        first, rows = np.zeros(nt, np.int32), np.zeros(nt, np.int32)
+        rp = np.zeros(n + 1, np.int32)
+        col = np.zeros(max(nnz, 1), np.int32)
+        val = np.zeros(max(nnz, 1))
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        _L.check(self.lib.kmcf_matrix_sum_plan(self.handle, None, ip(first), ip(rows), ip(rp) if with_csr else None,
+                                               ip(col) if with_csr else None,
+                                               val.ctypes.data_as(C.POINTER(C.c_double)) if with_csr else None),
+                 "kmcf_matrix_sum_plan")
+        out["tile_first"], out["tile_rows"] = first[:pl.sell_tiles], rows[:pl.sell_tiles]
+        if with_csr:
+            out["row_ptr"], out["col"], out["val"] = rp, col[:nnz], val[:nnz]
+        out["perm"] = self.row_order()[0]
+        return out
+
     def neighbours(self):
         """[(rank, nnz, cols_per_neighbour, rows_per_neighbour), ...] starting with self."""
         out = []

@@ -149,6 +149,29 @@ int kmcf_matrix_neighbour(const kmcf_matrix *m, int k, int *neighbour_rank, int 
  * the order was not refined for that layout). */
 int kmcf_matrix_row_order(const kmcf_matrix *m, int *h_perm, int *n_short, int *h_tile_end, int *n_tiles);
 
+/* Summation order of the solver kernels for inspection (no reference counterpart).  The CG's dot products and the
+ * SpMV's row sums are deterministic: one partial per block, blocks and lanes added in a fixed order that depends
+ * only on the quantities below.  tests/ feed them to the CPU oracle, which then adds in the same order and must
+ * reproduce the device's iterates bit for bit (oracle/kmcf_oracle_order.c). */
+typedef struct {
+    int rows, n_short, halo_cols;
+    int vec_grid;           /* blocks of the CG's vector kernels = r.z / b.b partials                           */
+    int sell_active;        /* 1: the row-per-lane coded kernel computes the short rows (else: see spmv_kind)    */
+    int sell_ident;         /* 1: lane t of a tile owns internal row first + t                                   */
+    int sell_grid;          /* its blocks = p.Ap partials of the interior pass                                   */
+    int sell_tiles;
+    int boundary_grid, boundary_lpr, boundary_rows;   /* separate pass over the rows that touch the halo (0: none) */
+    int long_items;         /* chunks of the long-row kernel (0: none)                                           */
+    int sub_grid;           /* blocks of the tunnel sub-block operator (0: none)                                 */
+    int cg_variant;         /* recurrence a solve on this matrix runs now: 0 classic (reference order), 1 single-reduction */
+    int reserved[3];
+} kmcf_sum_plan_t;
+/* h_tile_first / h_tile_rows: first internal row and row count of every row-per-lane tile (sell_tiles entries each;
+ * NULL: skip).  h_row_ptr / h_col / h_val: the CSR as stored (internal row order, entries of a row in creation
+ * order, own columns as internal row ids, halo columns as rows + halo slot; NULL: skip). */
+int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan, int *h_tile_first, int *h_tile_rows,
+                         int *h_row_ptr, int *h_col, double *h_val);
+
 /* Overwrite the values (same order as the CSR given at creation). */
 int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val);
 /* Copy the values back (creation order). */

@@ -202,6 +202,60 @@ def pcg_jacobi(row_ptr, col, val, rhs, x0, dinv, tol, max_it, P=1, fixed_iters=0
     return x, it, rel.value
 
 
+def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode=1, val=None, history=False):
+    """The reference's (P)CG added in the device's order (kmcf_oracle_order.c).  `plan`: what the library exports
+    with kmcf_matrix_sum_plan / kmcf_matrix_row_order (a dict: vec_grid, sell_grid, tile_first, tile_rows, row_ptr,
+    col, val in the internal row order, perm = caller row of every internal row).  rhs / x0 / dinv in the CALLER's
+    row order (dinv None: unpreconditioned).  Returns dict(x, r, iterations, bb, rz, relres, converged[, rz_hist])."""
+    L = lib()
+    if not hasattr(L, "_order_ready"):
+        L.orc_pcg_device_order.restype = C.c_int
+        L.orc_pcg_device_order.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+        L.orc_spmv_device_order.argtypes = [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L._order_ready = True
+    assert plan["sell_active"] and plan["sell_ident"] and plan["n_short"] == plan["rows"] and not plan["halo_cols"] \
+        and not plan["sub_grid"], "device-order oracle: single-rank matrix computed by the row-per-lane kernel only"
+    perm = _i(plan["perm"])
+    n = len(perm)
+    r = _f(rhs)[perm].copy()
+    x = _f(x0)[perm].copy()
+    dv = _f(dinv)[perm].copy() if dinv is not None else np.ones(n)
+    bb, rz, done = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+    hist = np.zeros(max(int(max_it), int(fixed_iters)) + 2) if history else None
+    it = L.orc_pcg_device_order(n, _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"] if val is None else val), r, x, dv,
+                                1 if dinv is not None else 0, float(tol), int(max_it), int(fixed_iters), int(check_mode),
+                                int(plan["vec_grid"]), int(plan["sell_grid"]), len(plan["tile_first"]),
+                                _i(plan["tile_first"]), _i(plan["tile_rows"]), C.byref(bb), C.byref(rz), C.byref(done),
+                                hist.ctypes.data_as(C.c_void_p) if history else None)
+    xo, ro = np.empty(n), np.empty(n)
+    xo[perm] = x
+    ro[perm] = r
+    out = dict(x=xo, r=ro, iterations=it, bb=bb.value, rz=rz.value, converged=bool(done.value),
+               relres=float(np.sqrt(rz.value / bb.value)) if bb.value > 0 else 0.0)
+    if history:
+        out["rz_hist"] = hist[:it + 1]
+    return out
+
+
+def spmv_device_order(plan, x_user):
+    """y = A x with every row added in the row-per-lane kernel's order; caller's row order in and out."""
+    pcg_device_order.__doc__  # (argtypes are set up there)
+    L = lib()
+    if not hasattr(L, "_order_ready"):
+        L.orc_spmv_device_order.argtypes = [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _dp, _dp, _dp]
+    perm = _i(plan["perm"])
+    n = len(perm)
+    x = _f(x_user)[perm].copy()
+    y = np.zeros(n)
+    L.orc_spmv_device_order(len(plan["tile_first"]), _i(plan["tile_first"]), _i(plan["tile_rows"]), int(plan["sell_grid"]),
+                            _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"]), x, y)
+    out = np.empty(n)
+    out[perm] = y
+    return out
+
+
 def pcg_jacobi_omp(row_ptr, col, val, rhs, x0, dinv, tol, max_it, fixed_iters=0):
     n = len(row_ptr) - 1
     r = _f(rhs).copy()

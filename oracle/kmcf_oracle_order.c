@@ -1,0 +1,246 @@
+/*
+ * kmcf_oracle_order.c -- CPU oracle, part 3: the reference's Jacobi-PCG in the SUMMATION ORDER of libkmcfield.
+ *
+ * TEST INFRASTRUCTURE ONLY (see kmcf_oracle.c): imported by tests/ and __graft_entry__.smoke(), never by the
+ * product package.
+ *
+ * Why this file exists.  The algorithm is the reference's (iterative_solver::conjugate_gradient_jacobi,
+ * dist_iterative/dist_conjugate_gradient.cpp:149-276; conjugate_gradient :17-121; the absolute rule of
+ * solve_sparse_CG_Jacobi, src/iterative_solvers_gpu.cu:838-858): same recurrence, same operation order, same
+ * stopping rule -- orc_pcg_jacobi in kmcf_oracle.c restates it with the rows in the caller's order and pairwise
+ * dots.  But the K system spans conductances 1 ... 1e-8 and is solved to 1e-14 N: the iteration count at which
+ * r.z/b.b crosses tol^2 moves by +-3 % with the ORDER in which a dot product's terms are added (316 ... 328 on the
+ * 5 nm device), so two correct implementations cannot be compared by their counts unless they add in the same
+ * order.  The device's order is deterministic (one partial per block, lanes / waves / blocks added in a fixed
+ * tree, kmcf_cg.hip + kmcf_spmv.hip) and is a function of a few integers that the library exports
+ * (kmcf_matrix_sum_plan).  This file adds in exactly that order; the result must then agree with the device
+ * BIT FOR BIT -- every iterate, every r.z, the iteration count -- which is what tests/test_gpu_parity.py checks.
+ *
+ * Each function names the device code whose order it follows (csrc/...), and the reference lines of the
+ * operation it performs.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BLK 256
+
+/* wave_sum64 (csrc/kmcf_cg.hip): xor butterfly over 64 lanes, offsets 32, 16 ... 1; every lane ends with the total */
+static double wave_sum64(const double *v)
+{
+    double a[64], b[64];
+    memcpy(a, v, sizeof(a));
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ off];
+        memcpy(a, b, sizeof(a));
+    }
+    return a[0];
+}
+
+/* the same over groups of `width` lanes (wave_sum_width, csrc/kmcf_spmv.hip): offsets < width only; returns lane 0 of
+ * the group that starts at v */
+static double group_sum(const double *v, int width)
+{
+    double a[64], b[64];
+    for (int l = 0; l < width; ++l) a[l] = v[l];
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (off >= width) continue;
+        for (int l = 0; l < width; ++l) b[l] = a[l] + a[l ^ off];
+        for (int l = 0; l < width; ++l) a[l] = b[l];
+    }
+    return a[0];
+}
+
+/* block_sum / block_sum_256: four wave sums, then (w0 + w1) + (w2 + w3) */
+static double block_sum(const double *v /* BLK */)
+{
+    double w[4];
+    for (int k = 0; k < 4; ++k) w[k] = wave_sum64(v + 64 * k);
+    return (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+/* reduce_partials (csrc/kmcf_cg.hip): thread t adds p[q][t], p[q][t + 256] ... for q = 0 .. 3, then block_sum */
+static double reduce_partials(int narr, const double *const *p, const int *n)
+{
+    double v[BLK];
+    for (int t = 0; t < BLK; ++t) {
+        double s = 0.0;
+        for (int q = 0; q < narr; ++q)
+            for (int i = t; i < n[q]; i += BLK) s += p[q][i];
+        v[t] = s;
+    }
+    return block_sum(v);
+}
+
+static double reduce1(const double *p, int n)
+{
+    const double *pp[1] = {p};
+    return reduce_partials(1, pp, &n);
+}
+
+/* One row of the row-per-lane coded kernel (spmv_sell_kernel, csrc/kmcf_spmv.hip): the off-diagonal products in
+ * the row's stored order, one add each, then the diagonal product (first entry whose column is the row). */
+static double row_sum_diag_last(int i, const int *rp, const int *col, const double *val, const double *x)
+{
+    int dp = -1;
+    for (int j = rp[i]; j < rp[i + 1]; ++j)
+        if (col[j] == i) { dp = j; break; }
+    double s = 0.0;
+    for (int j = rp[i]; j < rp[i + 1]; ++j)
+        if (j != dp) s += val[j] * x[col[j]];
+    const double dg = dp >= 0 ? val[dp] : 0.0;
+    s += dg * x[i];
+    return s;
+}
+
+/* Ap = A p over the tiles of the row-per-lane kernel + the p.Ap partial of every block: block b walks tiles
+ * c = xcd Cx + bi + k nb8 (xcd = b & 7, bi = b >> 3, nb8 = grid / 8, Cx = ceil(tiles / 8)); lane t of a tile owns
+ * row first + t and adds x[row] * Ap[row] to its dot after every tile. */
+static void spmv_sell_order(int n_tiles, const int *tile_first, const int *tile_rows, int grid, const int *rp,
+                            const int *col, const double *val, const double *x, double *y, double *part /* grid or NULL */)
+{
+    const int nb8 = grid >> 3, Cx = (n_tiles + 7) >> 3;
+    for (int b = 0; b < grid; ++b) {
+        const int xcd = b & 7, bi = b >> 3;
+        int gmax = n_tiles - xcd * Cx;
+        if (gmax > Cx) gmax = Cx;
+        const int nt = gmax > bi ? (gmax - bi + nb8 - 1) / nb8 : 0;
+        double dot[BLK];
+        for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+        for (int k = 0; k < nt; ++k) {
+            const int c = xcd * Cx + bi + k * nb8;
+            for (int t = 0; t < tile_rows[c]; ++t) {
+                const int row = tile_first[c] + t;
+                const double s = row_sum_diag_last(row, rp, col, val, x);
+                y[row] = s;
+                dot[t] += x[row] * s;
+            }
+        }
+        if (part) part[b] = block_sum(dot);
+    }
+}
+
+/* r.z partials as cg_xr_kernel forms them: two rows per lane and step (double2), thread (b, t) takes pairs
+ * b 256 + t, + grid 256, ...; the odd last row goes to thread 0 of block 0 after its pairs. */
+static void rz_partials_pairs(int n, int grid, const double *r, const double *z, double *part)
+{
+    const int n2 = n >> 1, T = grid * BLK;
+    double *acc = (double *)calloc((size_t)T, sizeof(double));
+    for (int i = 0; i < n2; ++i) {
+        double *a = &acc[i % T];
+        *a += r[2 * i] * z[2 * i];
+        *a += r[2 * i + 1] * z[2 * i + 1];
+    }
+    if (n & 1) acc[0] += r[n - 1] * z[n - 1];
+    for (int b = 0; b < grid; ++b) part[b] = block_sum(acc + (size_t)b * BLK);
+    free(acc);
+}
+
+/*
+ * Classic loop of one rank (pcg_loop, csrc/kmcf_cg.hip) on a matrix whose short rows are all computed by the
+ * row-per-lane kernel.  All arrays in the library's INTERNAL row order (kmcf_matrix_sum_plan exports the CSR in
+ * that order; the caller permutes the vectors with kmcf_matrix_row_order's perm).
+ *   r  in: rhs, out: residual;  x  in: start guess, out: solution;  dinv: 1/diag (ignored when !precond)
+ *   check_mode 1: r.z/b.b > tol^2 (dist_conjugate_gradient.cpp:217)
+ *              2: first test sqrt(r.z) > tol^2, later ones r.z > tol^2 (src/iterative_solvers_gpu.cu:838-858)
+ *   fixed_iters > 0: exactly that many iterations, no test
+ * rz_hist (may be NULL, max_it + 2 entries): r.z as seen by the loop head of iteration k (index k - 1).
+ * Returns the iterations executed; *bb_out, *rz_out as kmcf_solve_stats_t reports them.
+ */
+int orc_pcg_device_order(int n, const int *rp, const int *col, const double *val, double *r, double *x, const double *dinv,
+                         int precond, double tol, int max_it, int fixed_iters, int check_mode, int vec_grid,
+                         int sell_grid, int n_tiles, const int *tile_first, const int *tile_rows, double *bb_out,
+                         double *rz_out, int *done_out, double *rz_hist)
+{
+    const int G = vec_grid, T = G * BLK;
+    double *p = (double *)malloc(((size_t)n + 1) * sizeof(double));
+    double *Ap = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *z = (double *)malloc(((size_t)n + 1) * sizeof(double));
+    double *part_a = (double *)calloc((size_t)sell_grid + 1, sizeof(double));
+    double *part_b = (double *)calloc((size_t)G, sizeof(double));
+    double *part_c = (double *)calloc((size_t)G, sizeof(double));
+    double *acc1 = (double *)malloc((size_t)T * sizeof(double)), *acc2 = (double *)malloc((size_t)T * sizeof(double));
+    const double tol2 = tol * tol;
+    /* p <- x0 ; Ap = A x0 (:178-191) */
+    memcpy(p, x, (size_t)n * sizeof(double));
+    spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, p, Ap, NULL);
+    /* cg_init_kernel: r = b - A x0, z, partial r.z and b.b (:187, 201-212); one row per lane and step */
+    for (int i = 0; i < T; ++i) acc1[i] = acc2[i] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double b = r[i];
+        acc2[i % T] += b * b;
+        const double ri = b + (-1.0) * Ap[i];
+        r[i] = ri;
+        z[i] = precond ? ri * dinv[i] : ri;
+        acc1[i % T] += ri * z[i];
+    }
+    for (int b = 0; b < G; ++b) { part_b[b] = block_sum(acc1 + (size_t)b * BLK); part_c[b] = block_sum(acc2 + (size_t)b * BLK); }
+
+    double bb = 0.0, rz_par[2] = {0.0, 0.0}, rz_last = 0.0, xa = 0.0;
+    int pending = 0, iters = 0, done = 0;
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    for (int k = 1; k <= limit; ++k) {
+        const int parity = k & 1, first = k == 1;
+        /* ---- cg_p_kernel: loop head (:217-227) + the x += alpha p of iteration k - 1 (:246) */
+        const double rz_new = reduce1(part_b, G);
+        if (first) bb = reduce1(part_c, G);
+        int go = 1;
+        if (fixed_iters <= 0) {
+            if (check_mode == 1) go = rz_new / bb > tol2;
+            else go = (first ? sqrt(rz_new) : rz_new) > tol2;
+        }
+        rz_last = rz_new;
+        if (rz_hist) rz_hist[k - 1] = rz_new;
+        if (!go) {
+            if (pending) for (int i = 0; i < n; ++i) x[i] = x[i] + xa * p[i];
+            pending = 0;
+            done = 1;
+            break;
+        }
+        rz_par[parity] = rz_new;
+        iters += 1;
+        if (first) {
+            memcpy(p, z, (size_t)n * sizeof(double));                       /* :226 */
+        } else {
+            const double beta = rz_new / rz_par[parity ^ 1];                /* :220 */
+            for (int i = 0; i < n; ++i) {
+                if (pending) x[i] = x[i] + xa * p[i];
+                p[i] = beta * p[i] + z[i];                                  /* :221-222 */
+            }
+        }
+        /* ---- SpMV + p.Ap partials (:232-241) */
+        spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, p, Ap, part_a);
+        /* ---- cg_xr_kernel: alpha, r, z, r.z partials (:243-265); x stays pending */
+        const double pAp = reduce1(part_a, sell_grid);
+        const double a = rz_par[parity] / pAp, na = -a;
+        for (int i = 0; i < n; ++i) {
+            r[i] = r[i] + na * Ap[i];
+            z[i] = precond ? r[i] * dinv[i] : r[i];
+        }
+        rz_partials_pairs(n, G, r, z, part_b);
+        xa = a;
+        pending = 1;
+    }
+    if (!done) {
+        /* cg_tail_kernel + cg_x_kernel: the loop condition once more (:217), the pending update */
+        rz_last = reduce1(part_b, G);
+        if (rz_hist) rz_hist[limit] = rz_last;
+        if (pending) for (int i = 0; i < n; ++i) x[i] = x[i] + xa * p[i];
+    }
+    *bb_out = bb;
+    *rz_out = rz_last;
+    *done_out = done;
+    free(p); free(Ap); free(z); free(part_a); free(part_b); free(part_c); free(acc1); free(acc2);
+    return iters;
+}
+
+/* y = A x in the row-per-lane kernel's order (for SpMV parity at bit level) */
+void orc_spmv_device_order(int n_tiles, const int *tile_first, const int *tile_rows, int sell_grid, const int *rp,
+                           const int *col, const double *val, const double *x, double *y)
+{
+    spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, x, y, NULL);
+}
+
+/* kept for later parts of this file (boundary-row pass): silence -Wunused */
+double orc_group_sum_probe(const double *v, int width) { return group_sum(v, width); }

@@ -346,8 +346,9 @@ int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count);
 // returns at once (on every rank alike) when skip_if_done and S->done
 int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, kmcf_scalars *d_S, int skip_if_done);
 int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem);
-int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8);
-int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8);
+int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8);
+int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8,
+                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo);
 void kmcf_p2p_matrix_free(kmcf_matrix *m);
 int kmcf_p2p_halo_exchange(kmcf_matrix *m);
 // matrix.hip

@@ -317,17 +317,21 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     // checks the same at exchange time).  One small all-gather at build time; with the peer-to-peer transport the
     // same table tells every sender where in the receiver's window its data and its flag go.
     if (P > 1 && c->connected && (c->p2p_active || !c->group)) {
-        const int W = 4 * P;                      // per rank: sent to q | expected from q | landing offset | flag offset (8-byte units)
+        // per rank: sent to q | expected from q | landing offset | flag offset | acknowledgement offset (8-byte units, in
+        // this rank's window, for what q sends) | this rank's halo size (= distance between its two landing buffers)
+        const int W = 6 * P;
         std::vector<int> tab((size_t)W * P, 0), cnt(P, W), dsp(P);
         for (int q = 0; q < P; ++q) dsp[q] = W * q;
-        int land8 = 0, flag8 = 0;
-        if (c->p2p_active) KMCF_TRY(kmcf_p2p_matrix_alloc(m, &land8, &flag8));
+        int land8 = 0, flag8 = 0, ack8 = 0;
+        if (c->p2p_active) KMCF_TRY(kmcf_p2p_matrix_alloc(m, &land8, &flag8, &ack8));
         for (int k = 1; k < nnb; ++k) {
             const int q = m->neighbours[k];
             tab[(size_t)W * rank + q] = (int)m->rows_per_neighbour[k].size();
             tab[(size_t)W * rank + P + q] = (int)m->cols_per_neighbour[k].size();
             tab[(size_t)W * rank + 2 * P + q] = land8 + m->halo_offset[k];       // neighbour q's values land at its halo slots
             tab[(size_t)W * rank + 3 * P + q] = flag8 + (k - 1);
+            tab[(size_t)W * rank + 4 * P + q] = ack8 + (k - 1);                  // q acknowledges MY puts here
+            tab[(size_t)W * rank + 5 * P + q] = std::max(m->n_halo, 1);
         }
         int *d_tab = nullptr;
         KMCF_TRY(dev_upload(&d_tab, tab));
@@ -343,13 +347,15 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
                            "kmcf_matrix_build: rank %d sends %d halo values to rank %d, which expects %d (matrix not structurally symmetric?)",
                            a, tab[(size_t)W * a + b], b, tab[(size_t)W * b + P + a]);
         if (c->p2p_active) {
-            std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0);
+            std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0), r_ack((size_t)nnb, 0), r_halo((size_t)nnb, 0);
             for (int k = 1; k < nnb; ++k) {
                 const int q = m->neighbours[k];
                 r_land[k] = tab[(size_t)W * q + 2 * P + rank];
                 r_flag[k] = tab[(size_t)W * q + 3 * P + rank];
+                r_ack[k] = tab[(size_t)W * q + 4 * P + rank];
+                r_halo[k] = tab[(size_t)W * q + 5 * P + rank];
             }
-            KMCF_TRY(kmcf_p2p_matrix_connect(m, r_land, r_flag));
+            KMCF_TRY(kmcf_p2p_matrix_connect(m, r_land, r_flag, r_ack, r_halo));
         }
     }
     guard.m = nullptr;

@@ -15,9 +15,13 @@
 //   * all-gatherv = (once per KMC step: charges, solution, tunnel sub-vector) stage my slice in my window, raise
 //                   flags, pull the peers' slices, acknowledge.
 // Flags are sequence numbers (monotonic, never reset): store data -> system-scope fence -> flag store (release);
-// poll with acquire loads.  Slots are reused by parity: a rank can be at most one all-reduce ahead of another
-// (it needs every peer's contribution to finish one), and a halo landing zone is rewritten only after the
-// all-reduce that follows its SpMV, i.e. after its owner has consumed it.  EVERY wait is bounded (wall clock): on
+// poll with acquire loads.  All-reduce slots are reused by parity: a rank can be at most one all-reduce ahead of
+// another (it needs every peer's contribution to finish one).  The halo protocol assumes NOTHING about what runs
+// between two exchanges: landing zones are double-buffered by sequence parity and every consumer acknowledges the
+// sequence it has finished reading into the SENDER's window; put(s) first waits (on its own window: local memory)
+// for ack >= s - 2, so buffer s & 1 is rewritten only after its previous content (s - 2) was consumed, and a flag
+// that already reads s + 1 when the consumer of s looks at it still means "buffer s & 1 holds s" (s + 2 cannot have
+// been put).  Back-to-back SpMVs, the CG's initial A x0 followed by A z, benches: all safe.  EVERY wait is bounded (wall clock): on
 // expiry the kernel records an error and returns, later waits return at once, and the host reports KMCF_ERR_COMM
 // -- no hang.  RCCL stays available as the fallback transport and as the cross-check (tests compare iterates).
 //
@@ -56,11 +60,14 @@ struct kmcf_p2p {
 
 // per-matrix state of the halo protocol
 struct kmcf_p2p_halo {
-    double **d_put_ptr = nullptr;            // remote address of every packed entry
+    double **d_put_ptr = nullptr;            // remote address of every packed entry (buffer 0 of the receiver's landing zone)
+    long long *d_put_stride = nullptr;       // per packed entry: doubles from buffer 0 to buffer 1 there (the receiver's halo size)
     u64 **d_put_flag = nullptr;              // remote flag per neighbour (k >= 1)
-    size_t land_off = 0, flag_off = 0;       // own landing zone (n_halo doubles) and flags (nnb - 1) in my window
+    u64 **d_ack_ptr = nullptr;               // per neighbour: where I acknowledge ITS puts (in its window)
+    size_t land_off = 0, flag_off = 0;       // own landing zone (2 x n_halo doubles) and flags (nnb - 1) in my window
+    size_t ack_off = 0;                      // acknowledgements of MY puts, written by the neighbours (nnb - 1) in my window
     u64 seq = 0;
-    unsigned int *d_ctr = nullptr;
+    unsigned int *d_ctr = nullptr;           // [0] put: last block raises the flags; [1] wait: last block acknowledges
 };
 
 namespace {
@@ -153,14 +160,22 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_parts_kernel(char *c
     }
 }
 
-// pack + put: p[send_idx[i]] -> the neighbour's landing zone; the last block to finish raises the neighbours' flags
+// pack + put: p[send_idx[i]] -> buffer (seq & 1) of the neighbour's landing zone, once every neighbour has
+// acknowledged seq - 2 (the buffer's previous content); the last block to finish raises the neighbours' flags
 __global__ __launch_bounds__(KMCF_BLOCK) void p2p_put_kernel(int n_send, const int *__restrict__ send_idx, const double *__restrict__ p,
-                                                             double *const *__restrict__ put_ptr, int n_nb, u64 *const *__restrict__ put_flag,
-                                                             u64 seq, unsigned int *__restrict__ ctr)
+                                                             double *const *__restrict__ put_ptr, const long long *__restrict__ put_stride,
+                                                             int n_nb, u64 *const *__restrict__ put_flag, const u64 *__restrict__ acks,
+                                                             u64 seq, long long timeout, int *d_err, int *h_err,
+                                                             unsigned int *__restrict__ ctr)
 {
     __shared__ int s_last;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_send; i += gridDim.x * blockDim.x)
-        __hip_atomic_store(reinterpret_cast<u64 *>(put_ptr[i]), (u64)__double_as_longlong(p[send_idx[i]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < n_nb && seq > 2) wait_ge(&acks[threadIdx.x], seq - 2, timeout, d_err, h_err, 5);
+    __syncthreads();
+    const long long par = (long long)(seq & 1);
+    if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)      // (never overwrite an unconsumed buffer)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_send; i += gridDim.x * blockDim.x)
+            __hip_atomic_store(reinterpret_cast<u64 *>(put_ptr[i] + par * put_stride[i]), (u64)__double_as_longlong(p[send_idx[i]]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -173,16 +188,26 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_put_kernel(int n_send, const i
     if (threadIdx.x == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// wait for the flags of all neighbours, then move the landing zone behind p_local
+// wait for the flags of all neighbours, move buffer (seq & 1) of the landing zone behind p_local, then -- the last
+// block to finish -- acknowledge seq to every sender (into ITS window)
 __global__ __launch_bounds__(KMCF_BLOCK) void p2p_halo_wait_kernel(int n_nb, const u64 *__restrict__ flags, u64 seq, long long timeout,
                                                                    int *d_err, int *h_err, int n_halo, const double *__restrict__ landing,
-                                                                   double *__restrict__ halo_dst)
+                                                                   double *__restrict__ halo_dst, u64 *const *__restrict__ ack_ptr,
+                                                                   unsigned int *__restrict__ ctr)
 {
+    __shared__ int s_last;
     if ((int)threadIdx.x < n_nb) wait_ge(&flags[threadIdx.x], seq, timeout, d_err, h_err, 2);
     __syncthreads();
     if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const double *src = landing + (size_t)(seq & 1) * n_halo;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_halo; i += gridDim.x * blockDim.x)
-        halo_dst[i] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&landing[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        halo_dst[i] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    __syncthreads();                                     // every load of this block has returned (its value was stored)
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if ((int)threadIdx.x < n_nb) store_release_system(ack_ptr[threadIdx.x], seq);
+    if (threadIdx.x == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // gather, step 1: my slice into my staging half (after every peer has consumed what was there two gathers ago),
@@ -361,10 +386,11 @@ int kmcf_p2p_check(kmcf_comm *c)
     // (a transport that failed and was switched off -- bench.py's trial, KMCF_TRANSPORT=auto -- must not fail the calls
     // that now run over RCCL; kmcf_comm_select_transport refuses to switch it on again)
     if (!c->p2p_active) return KMCF_OK;
-    static const char *what[] = {"", "all-reduce", "halo exchange", "all-gather (data)", "all-gather (acknowledgement)"};
+    static const char *what[] = {"", "all-reduce", "halo exchange", "all-gather (data)", "all-gather (acknowledgement)",
+                                 "halo exchange (acknowledgement of the put before last)"};
     const int code = *c->p2p->h_err;
     kmcf_set_error("p2p transport: rank %d timed out in %s -- a peer did not arrive within the bound (KMCF_P2P_TIMEOUT_MS)", c->rank,
-                   code >= 1 && code <= 4 ? what[code] : "a wait");
+                   code >= 1 && code <= 5 ? what[code] : "a wait");
     return KMCF_ERR_COMM;
 }
 
@@ -426,43 +452,56 @@ int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
 }
 
 // ---------------------------------------------------------------- halo protocol of one matrix
-int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8)
+int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8)
 {
     kmcf_p2p *w = m->comm->p2p;
     kmcf_p2p_halo *h = new kmcf_p2p_halo();
     m->p2p = h;
     const int n_nb = m->number_of_neighbours - 1;
     h->land_off = align_up(w->bump, 256);
-    h->flag_off = align_up(h->land_off + (size_t)std::max(m->n_halo, 1) * sizeof(double), 256);
-    const size_t end = h->flag_off + (size_t)std::max(n_nb, 1) * sizeof(u64);
+    h->flag_off = align_up(h->land_off + 2 * (size_t)std::max(m->n_halo, 1) * sizeof(double), 256);     // two buffers (sequence parity)
+    h->ack_off = align_up(h->flag_off + (size_t)std::max(n_nb, 1) * sizeof(u64), 256);
+    const size_t end = h->ack_off + (size_t)std::max(n_nb, 1) * sizeof(u64);
     KMCF_CHECK(end <= w->win_bytes, KMCF_ERR_NOMEM, "p2p window exhausted (%zu of %zu bytes; KMCF_P2P_WINDOW_MB)", end, w->win_bytes);
     w->bump = end;
-    KMCF_HIP(hipMemset(w->win + h->flag_off, 0, (size_t)std::max(n_nb, 1) * sizeof(u64)));
-    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_ctr), sizeof(unsigned int)));
-    KMCF_HIP(hipMemset(h->d_ctr, 0, sizeof(unsigned int)));
+    KMCF_HIP(hipMemset(w->win + h->flag_off, 0, end - h->flag_off));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_ctr), 2 * sizeof(unsigned int)));
+    KMCF_HIP(hipMemset(h->d_ctr, 0, 2 * sizeof(unsigned int)));
     *land_off8 = (int)(h->land_off / 8);
     *flag_off8 = (int)(h->flag_off / 8);
+    *ack_off8 = (int)(h->ack_off / 8);
     return KMCF_OK;
 }
 
-// r_land8[k], r_flag8[k] (k >= 1): where neighbour k wants MY data / flag inside ITS window (units of 8 bytes)
-int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8)
+// r_land8[k], r_flag8[k], r_ack8[k] (k >= 1): where neighbour k wants MY data / my flag / my acknowledgement of ITS
+// puts inside ITS window (units of 8 bytes); r_halo[k]: its halo size = distance between its two landing buffers
+int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8,
+                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo)
 {
     kmcf_p2p *w = m->comm->p2p;
     kmcf_p2p_halo *h = m->p2p;
     const int nnb = m->number_of_neighbours;
     std::vector<double *> put((size_t)std::max(m->n_send, 1), nullptr);
-    std::vector<u64 *> flg((size_t)std::max(nnb - 1, 1), nullptr);
+    std::vector<long long> stride((size_t)std::max(m->n_send, 1), 0);
+    std::vector<u64 *> flg((size_t)std::max(nnb - 1, 1), nullptr), ack((size_t)std::max(nnb - 1, 1), nullptr);
     for (int k = 1; k < nnb; ++k) {
         char *base = w->peer[m->neighbours[k]];
         double *land = reinterpret_cast<double *>(base) + r_land8[k];
-        for (size_t i = 0; i < m->rows_per_neighbour[k].size(); ++i) put[(size_t)m->send_offset[k] + i] = land + i;
+        for (size_t i = 0; i < m->rows_per_neighbour[k].size(); ++i) {
+            put[(size_t)m->send_offset[k] + i] = land + i;
+            stride[(size_t)m->send_offset[k] + i] = r_halo[k];
+        }
         flg[(size_t)k - 1] = reinterpret_cast<u64 *>(base) + r_flag8[k];
+        ack[(size_t)k - 1] = reinterpret_cast<u64 *>(base) + r_ack8[k];
     }
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_put_ptr), put.size() * sizeof(double *)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_put_stride), stride.size() * sizeof(long long)));
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_put_flag), flg.size() * sizeof(u64 *)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_ack_ptr), ack.size() * sizeof(u64 *)));
     KMCF_HIP(hipMemcpy(h->d_put_ptr, put.data(), put.size() * sizeof(double *), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(h->d_put_stride, stride.data(), stride.size() * sizeof(long long), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(h->d_put_flag, flg.data(), flg.size() * sizeof(u64 *), hipMemcpyHostToDevice));
+    KMCF_HIP(hipMemcpy(h->d_ack_ptr, ack.data(), ack.size() * sizeof(u64 *), hipMemcpyHostToDevice));
     return KMCF_OK;
 }
 
@@ -470,7 +509,9 @@ void kmcf_p2p_matrix_free(kmcf_matrix *m)
 {
     if (!m->p2p) return;
     if (m->p2p->d_put_ptr) hipFree(m->p2p->d_put_ptr);
+    if (m->p2p->d_put_stride) hipFree(m->p2p->d_put_stride);
     if (m->p2p->d_put_flag) hipFree(m->p2p->d_put_flag);
+    if (m->p2p->d_ack_ptr) hipFree(m->p2p->d_ack_ptr);
     if (m->p2p->d_ctr) hipFree(m->p2p->d_ctr);
     delete m->p2p;
     m->p2p = nullptr;
@@ -487,11 +528,13 @@ int kmcf_p2p_halo_exchange(kmcf_matrix *m)
     KMCF_CHECK(h != nullptr, KMCF_ERR_STATE, "p2p halo: matrix was built before the transport was up");
     ++h->seq;
     const int g = std::max(1, std::min((m->n_send + KMCF_BLOCK - 1) / KMCF_BLOCK, 64));
-    p2p_put_kernel<<<g, KMCF_BLOCK, 0, c->comm_stream>>>(m->n_send, m->d_send_idx, m->d_p, h->d_put_ptr, n_nb, h->d_put_flag, h->seq, h->d_ctr);
+    p2p_put_kernel<<<g, KMCF_BLOCK, 0, c->comm_stream>>>(m->n_send, m->d_send_idx, m->d_p, h->d_put_ptr, h->d_put_stride, n_nb, h->d_put_flag,
+                                                         reinterpret_cast<const u64 *>(w->win + h->ack_off), h->seq, w->timeout_ticks, w->d_err,
+                                                         w->h_err, h->d_ctr);
     const int g2 = std::max(1, std::min((m->n_halo + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4), 32));
     p2p_halo_wait_kernel<<<g2, KMCF_BLOCK, 0, c->comm_stream>>>(n_nb, reinterpret_cast<const u64 *>(w->win + h->flag_off), h->seq, w->timeout_ticks,
                                                                w->d_err, w->h_err, m->n_halo, reinterpret_cast<const double *>(w->win + h->land_off),
-                                                               m->d_p + m->n_loc);
+                                                               m->d_p + m->n_loc, h->d_ack_ptr, h->d_ctr + 1);
     KMCF_HIP(hipGetLastError());
     return KMCF_OK;
 }

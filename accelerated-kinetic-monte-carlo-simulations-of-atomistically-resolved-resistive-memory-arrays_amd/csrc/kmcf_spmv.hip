@@ -1532,6 +1532,15 @@ extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan,
     return KMCF_OK;
 }
 
+extern "C" int kmcf_matrix_halo_columns(const kmcf_matrix *m, int *h_gid)
+{
+    KMCF_CHECK(m && (h_gid || m->n_halo == 0), KMCF_ERR_ARG, "kmcf_matrix_halo_columns: null argument");
+    for (int k = 1; k < m->number_of_neighbours; ++k)
+        for (size_t s = 0; s < m->cols_per_neighbour[k].size(); ++s)
+            h_gid[m->halo_offset[k] + (int)s] = m->displs[m->neighbours[k]] + m->cols_per_neighbour[k][s];
+    return KMCF_OK;
+}
+
 extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
 {
     // a rank that owns no rows (fewer rows than ranks) still takes part in the exchange; its vectors may be null

@@ -81,6 +81,7 @@ SIGNATURES = {
                                                   _IP, _DP, C.POINTER(_P)]),
     "kmcf_matrix_info": (C.c_int, [_P, C.POINTER(MatrixInfo)]),
     "kmcf_matrix_row_order": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
+    "kmcf_matrix_halo_columns": (C.c_int, [_P, _IP]),
     "kmcf_matrix_sum_plan": (C.c_int, [_P, C.POINTER(SumPlan), _IP, _IP, _IP, _IP, _DP]),
     "kmcf_matrix_neighbour": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _IP, _IP]),
     "kmcf_matrix_set_values": (C.c_int, [_P, _DP]),

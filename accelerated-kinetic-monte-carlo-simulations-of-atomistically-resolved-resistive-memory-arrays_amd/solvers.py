@@ -587,6 +587,9 @@ class Distributed_matrix:
         if with_csr:
             out["row_ptr"], out["col"], out["val"] = rp, col[:nnz], val[:nnz]
         out["perm"] = self.row_order()[0]
+        gid = np.zeros(max(pl.halo_cols, 1), np.int32)
+        _L.check(self.lib.kmcf_matrix_halo_columns(self.handle, ip(gid)), "kmcf_matrix_halo_columns")
+        out["halo_gid"] = gid[:pl.halo_cols]
         return out
 
     def neighbours(self):

@@ -172,6 +172,9 @@ typedef struct {
 int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan, int *h_tile_first, int *h_tile_rows,
                          int *h_row_ptr, int *h_col, double *h_val);
 
+/* Global column of every halo slot (halo_cols entries; column n_loc + h of the stored CSR is global column h_gid[h]). */
+int kmcf_matrix_halo_columns(const kmcf_matrix *m, int *h_gid);
+
 /* Overwrite the values (same order as the CSR given at creation). */
 int kmcf_matrix_set_values(kmcf_matrix *m, const double *h_val);
 /* Copy the values back (creation order). */

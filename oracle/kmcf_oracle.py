@@ -202,7 +202,7 @@ def pcg_jacobi(row_ptr, col, val, rhs, x0, dinv, tol, max_it, P=1, fixed_iters=0
     return x, it, rel.value
 
 
-def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode=1, val=None, history=False):
+def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode=1, val=None, history=False, variant=None):
     """The reference's (P)CG added in the device's order (kmcf_oracle_order.c).  `plan`: what the library exports
     with kmcf_matrix_sum_plan / kmcf_matrix_row_order (a dict: vec_grid, sell_grid, tile_first, tile_rows, row_ptr,
     col, val in the internal row order, perm = caller row of every internal row).  rhs / x0 / dinv in the CALLER's
@@ -213,6 +213,10 @@ def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode
         L.orc_pcg_device_order.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+        L.orc_pcg1_device_order.restype = C.c_int
+        L.orc_pcg1_device_order.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
         L.orc_spmv_device_order.argtypes = [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _dp, _dp, _dp]
         L._order_ready = True
     assert plan["sell_active"] and plan["sell_ident"] and plan["n_short"] == plan["rows"] and not plan["halo_cols"] \
@@ -224,11 +228,18 @@ def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode
     dv = _f(dinv)[perm].copy() if dinv is not None else np.ones(n)
     bb, rz, done = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
     hist = np.zeros(max(int(max_it), int(fixed_iters)) + 2) if history else None
-    it = L.orc_pcg_device_order(n, _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"] if val is None else val), r, x, dv,
-                                1 if dinv is not None else 0, float(tol), int(max_it), int(fixed_iters), int(check_mode),
-                                int(plan["vec_grid"]), int(plan["sell_grid"]), len(plan["tile_first"]),
-                                _i(plan["tile_first"]), _i(plan["tile_rows"]), C.byref(bb), C.byref(rz), C.byref(done),
-                                hist.ctypes.data_as(C.c_void_p) if history else None)
+    # variant: the recurrence the library runs on this matrix (plan["cg_variant"]: 0 classic = the reference's
+    # operation order, 1 single-reduction) unless the caller names one
+    cg1r = plan["cg_variant"] == 1 if variant is None else variant == "cg1r"
+    common = (n, _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"] if val is None else val), r, x, dv,
+              1 if dinv is not None else 0, float(tol), int(max_it), int(fixed_iters))
+    tail = (int(plan["vec_grid"]), int(plan["sell_grid"]), len(plan["tile_first"]), _i(plan["tile_first"]),
+            _i(plan["tile_rows"]), C.byref(bb), C.byref(rz), C.byref(done), hist.ctypes.data_as(C.c_void_p) if history else None)
+    if cg1r:
+        assert check_mode == 1
+        it = L.orc_pcg1_device_order(*common, *tail)
+    else:
+        it = L.orc_pcg_device_order(*common, int(check_mode), *tail)
     xo, ro = np.empty(n), np.empty(n)
     xo[perm] = x
     ro[perm] = r
@@ -253,6 +264,221 @@ def spmv_device_order(plan, x_user):
                             _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"]), x, y)
     out = np.empty(n)
     out[perm] = y
+    return out
+
+
+class _DevPlan(C.Structure):
+    """orc_dev_plan (kmcf_oracle_order.c)"""
+    _ipt, _dpt = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    _fields_ = [("n", C.c_int), ("n_short", C.c_int), ("n_halo", C.c_int), ("rp", _ipt), ("col", _ipt), ("val", _dpt),
+                ("vec_grid", C.c_int), ("sell_grid", C.c_int), ("n_tiles", C.c_int), ("tile_first", _ipt), ("tile_rows", _ipt),
+                ("boundary_grid", C.c_int), ("boundary_lpr", C.c_int), ("n_boundary", C.c_int), ("boundary_rows", _ipt),
+                ("n_long_items", C.c_int), ("long_items", _ipt), ("sub_grid", C.c_int), ("sub_n", C.c_int), ("sub_rows", _ipt),
+                ("sub_rp", _ipt), ("sub_col", _ipt), ("sub_val", _dpt)]
+
+
+class DeviceRank:
+    """One rank of a solve in the device's summation order: the library's exported plan (kmcf_matrix_sum_plan: a dict)
+    turned into the arrays kmcf_oracle_order.c walks.  sub: the tunnel sub-block of the T operator on this rank,
+    dict(grid, rows = caller LOCAL row of every local sub row, row_ptr, col, val over the gathered sub-vector)."""
+    LONG_CHUNK = 2048                        # KMCF_LONG_CHUNK (csrc/kmcf_internal.hpp)
+
+    def __init__(self, plan, sub=None):
+        assert plan["sell_active"] and plan["sell_ident"], "device-order oracle: short rows must be computed by the row-per-lane kernel"
+        self.plan = plan
+        self.n, self.n_halo, self.n_short = int(plan["rows"]), int(plan["halo_cols"]), int(plan["n_short"])
+        self.perm = _i(plan["perm"])
+        self.inv = np.empty(self.n, np.int32)
+        self.inv[self.perm] = np.arange(self.n, dtype=np.int32)
+        self.rp, self.col, self.val = _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"])
+        self.halo_gid = _i(plan.get("halo_gid", np.zeros(0, np.int32)))
+        isb = np.zeros(self.n, bool)
+        rows_of = np.repeat(np.arange(self.n), np.diff(self.rp))
+        isb[rows_of[self.col >= self.n]] = True
+        self.boundary = _i(np.nonzero(isb[:self.n_short])[0])
+        items = []
+        for i in range(self.n_short, self.n):
+            first = len(items)
+            for j in range(int(self.rp[i]), int(self.rp[i + 1]), self.LONG_CHUNK):
+                items.append((i, j, min(j + self.LONG_CHUNK, int(self.rp[i + 1])), first))
+        self.long_items = _i(np.array(items, np.int32).reshape(-1)) if items else np.zeros(4, np.int32)
+        self.tile_first, self.tile_rows = _i(plan["tile_first"]), _i(plan["tile_rows"])
+        ipt, dpt = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        pi = lambda a: a.ctypes.data_as(ipt)
+        pd = lambda a: a.ctypes.data_as(dpt)
+        self.sub = sub
+        if sub is not None and len(sub["rows"]):
+            self.sub_rows = _i(self.inv[_i(sub["rows"])])
+            self.sub_rp, self.sub_col, self.sub_val = _i(sub["row_ptr"]), _i(sub["col"]), _f(sub["val"])
+            sub_n, sub_grid = len(self.sub_rows), int(sub["grid"])
+        else:
+            self.sub_rows = self.sub_rp = self.sub_col = np.zeros(1, np.int32)
+            self.sub_val = np.zeros(1)
+            sub_n = sub_grid = 0
+        self.c = _DevPlan(self.n, self.n_short, self.n_halo, pi(self.rp), pi(self.col), pd(self.val), int(plan["vec_grid"]),
+                          int(plan["sell_grid"]), len(self.tile_first), pi(self.tile_first), pi(self.tile_rows),
+                          int(plan["boundary_grid"]), int(plan["boundary_lpr"]), len(self.boundary), pi(self.boundary),
+                          len(items), pi(self.long_items), sub_grid, sub_n, pi(self.sub_rows), pi(self.sub_rp), pi(self.sub_col),
+                          pd(self.sub_val))
+        assert len(self.boundary) == int(plan["boundary_rows"]) or self.n_halo == 0
+        assert len(items) == int(plan["long_items"])
+
+
+def _order_lib():
+    L = lib()
+    if not hasattr(L, "_dev_ready"):
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.orc_dev_spmv.argtypes = [C.POINTER(_DevPlan), _dp, _dp, _dp, C.c_int, dp]
+        L.orc_dev_init.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, dp, dp]
+        L.orc_dev_p.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double]
+        L.orc_dev_x.argtypes = [C.c_int, _dp, _dp, C.c_double]
+        L.orc_dev_xr.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, _dp, dp]
+        L.orc_dev_cg1_update.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                         C.c_int, dp]
+        L._dev_ready = True
+    return L
+
+
+def pcg_device_order_ranks(ranks, counts, displs, rhs, x0, dinv, tol, max_it, fixed_iters=0, variant="classic",
+                           sub_counts=None, sub_displs=None, history=False):
+    """The reference's Jacobi-PCG over a group of ranks in the device's summation order: every rank's kernels by
+    kmcf_oracle_order.c, the halo exchange and the all-reduce (one partial per rank, added in rank order) here.
+    ranks: list of DeviceRank; counts / displs: the row partition; rhs, x0, dinv: GLOBAL vectors, caller's order
+    (dinv None: no preconditioner).  variant "classic" (pcg_loop: the reference's recurrence, two reductions) or
+    "cg1r" (pcg1_loop).  Returns dict(x, r (global), iterations, converged, bb, rz[, rz_hist])."""
+    L = _order_lib()
+    P = len(ranks)
+    pre = 1 if dinv is not None else 0
+    tol2 = float(tol) * float(tol)
+    st = []
+    for q, rk in enumerate(ranks):
+        sl = slice(int(displs[q]), int(displs[q]) + int(counts[q]))
+        g = lambda v: _f(v)[sl][rk.perm].copy()
+        st.append(dict(r=g(rhs), x=g(x0), dinv=g(dinv) if pre else np.ones(rk.n), xv=np.zeros(rk.n + rk.n_halo),
+                       Ap=np.zeros(rk.n + 1), z=np.zeros(rk.n), p=np.zeros(rk.n), s=np.zeros(rk.n)))
+    n_glob = int(displs[-1]) + int(counts[-1])
+    n_sub = int(sub_displs[-1]) + int(sub_counts[-1]) if sub_counts is not None else 0
+
+    def allreduce(vals):                       # one partial per rank, rank order (loopback_allreduce / p2p_allreduce_kernel)
+        acc = 0.0
+        for v in vals:
+            acc += v
+        return acc
+
+    def spmv(key, with_dot):
+        """Ap = A v on every rank for v = st[key] (own rows); returns the local p.Ap sums"""
+        glob = np.zeros(n_glob)
+        for q, rk in enumerate(ranks):
+            glob[int(displs[q]) + rk.perm] = st[q][key]
+        xsub = np.zeros(max(n_sub, 1))
+        if n_sub:
+            for q, rk in enumerate(ranks):
+                if rk.c.sub_n:
+                    xsub[int(sub_displs[q]):int(sub_displs[q]) + rk.c.sub_n] = st[q][key][rk.sub_rows]
+        out = []
+        for q, rk in enumerate(ranks):
+            xv = st[q]["xv"]
+            xv[:rk.n] = st[q][key]
+            if rk.n_halo:
+                xv[rk.n:] = glob[rk.halo_gid]
+            pap = C.c_double(0.0)
+            L.orc_dev_spmv(C.byref(rk.c), xv, xsub, st[q]["Ap"], 1 if with_dot else 0, C.byref(pap))
+            out.append(pap.value)
+        return out
+
+    hist = []
+    limit = int(fixed_iters) if fixed_iters > 0 else int(max_it)
+    iters, done, bb, rz_last = 0, False, 0.0, 0.0
+    if variant == "classic":
+        for q in range(P):
+            st[q]["p"][:] = st[q]["x"]
+        spmv("p", False)
+        loc = []
+        for q, rk in enumerate(ranks):
+            a, b = C.c_double(), C.c_double()
+            L.orc_dev_init(rk.n, rk.c.vec_grid, st[q]["r"], st[q]["Ap"], st[q]["dinv"], pre, st[q]["z"], C.byref(a), C.byref(b))
+            loc.append((a.value, b.value))
+        rz, bb = allreduce([v[0] for v in loc]), allreduce([v[1] for v in loc])
+        rz_par, xa, pending = [0.0, 0.0], 0.0, False
+        for k in range(1, limit + 1):
+            par, first = k & 1, k == 1
+            rz_new = rz
+            go = True if fixed_iters > 0 else (rz_new / bb > tol2)
+            rz_last = rz_new
+            hist.append(rz_new)
+            if not go:
+                if pending:
+                    for q, rk in enumerate(ranks):
+                        L.orc_dev_x(rk.n, st[q]["x"], st[q]["p"], xa)
+                pending, done = False, True
+                break
+            rz_par[par] = rz_new
+            iters += 1
+            beta = 0.0 if first else rz_new / rz_par[par ^ 1]
+            for q, rk in enumerate(ranks):
+                L.orc_dev_p(rk.n, st[q]["p"], st[q]["z"], st[q]["x"], beta, 1 if first else 0, 1 if pending else 0, xa)
+            pAp = allreduce(spmv("p", True))
+            a = rz_par[par] / pAp
+            loc = []
+            for q, rk in enumerate(ranks):
+                v = C.c_double()
+                L.orc_dev_xr(rk.n, rk.c.vec_grid, st[q]["r"], st[q]["Ap"], st[q]["dinv"], pre, a, st[q]["z"], C.byref(v))
+                loc.append(v.value)
+            rz = allreduce(loc)
+            xa, pending = a, True
+        if not done:
+            rz_last = rz
+            hist.append(rz)
+            if pending:
+                for q, rk in enumerate(ranks):
+                    L.orc_dev_x(rk.n, st[q]["x"], st[q]["p"], xa)
+    else:
+        for q in range(P):
+            st[q]["z"][:] = st[q]["x"]
+        spmv("z", False)
+        g_loc, b_loc = [], []
+        for q, rk in enumerate(ranks):
+            a, b = C.c_double(), C.c_double()
+            L.orc_dev_init(rk.n, rk.c.vec_grid, st[q]["r"], st[q]["Ap"], st[q]["dinv"], pre, st[q]["z"], C.byref(a), C.byref(b))
+            g_loc.append(a.value)
+            b_loc.append(b.value)
+        g_par, a_par = [0.0, 0.0], [0.0, 0.0]
+        for k in range(1, limit + 1):
+            par, first = k & 1, k == 1
+            d_loc = spmv("z", True)
+            gamma, delta = allreduce(g_loc), allreduce(d_loc)
+            if first:
+                bb = allreduce(b_loc)
+            go = True if fixed_iters > 0 else (gamma / bb > tol2)
+            if first:
+                beta, alpha = 0.0, gamma / delta
+            else:
+                beta = gamma / g_par[par ^ 1]
+                alpha = gamma / (delta - beta * gamma / a_par[par ^ 1])
+            rz_last = gamma
+            hist.append(gamma)
+            if not go:
+                done = True
+                break
+            g_par[par], a_par[par] = gamma, alpha
+            iters += 1
+            g_loc = []
+            for q, rk in enumerate(ranks):
+                v = C.c_double()
+                L.orc_dev_cg1_update(rk.n, rk.c.vec_grid, st[q]["x"], st[q]["r"], st[q]["p"], st[q]["s"], st[q]["z"], st[q]["Ap"],
+                                     st[q]["dinv"], pre, alpha, beta, 1 if first else 0, C.byref(v))
+                g_loc.append(v.value)
+        if not done:
+            rz_last = allreduce(g_loc)
+            hist.append(rz_last)
+    xo, ro = np.zeros(n_glob), np.zeros(n_glob)
+    for q, rk in enumerate(ranks):
+        xo[int(displs[q]) + rk.perm] = st[q]["x"]
+        ro[int(displs[q]) + rk.perm] = st[q]["r"]
+    out = dict(x=xo, r=ro, iterations=iters, converged=done or not ((rz_last / bb if bb else 0.0) > tol2), bb=bb, rz=rz_last,
+               relres=float(np.sqrt(rz_last / bb)) if bb > 0 else 0.0)
+    if history:
+        out["rz_hist"] = np.array(hist)
     return out
 
 

@@ -235,6 +235,93 @@ int orc_pcg_device_order(int n, const int *rp, const int *col, const double *val
     return iters;
 }
 
+/*
+ * Single-reduction loop of one rank (pcg1_loop, csrc/kmcf_cg.hip; Chronopoulos & Gear): the same Krylov iterates as
+ * the reference's recurrence in exact arithmetic, gamma = (r, z) and delta = (A z, z) reduced at one point.  The
+ * library runs it for multi-rank groups (one all-reduce per iteration) and under KMCF_CG_VARIANT=cg1r.
+ *   init : r = b - A x0 ; z = r .* dinv ; gamma = (r, z)                                  (cg1_init_kernel)
+ *   loop : w = A z, delta = (w, z) ; stop unless gamma / b.b > tol^2 ;
+ *          beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old) ;
+ *          p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = r .* dinv ; gamma' = (r, z)   (cg1_update_kernel)
+ * Arguments as orc_pcg_device_order.
+ */
+int orc_pcg1_device_order(int n, const int *rp, const int *col, const double *val, double *r, double *x, const double *dinv,
+                          int precond, double tol, int max_it, int fixed_iters, int vec_grid, int sell_grid, int n_tiles,
+                          const int *tile_first, const int *tile_rows, double *bb_out, double *rz_out, int *done_out,
+                          double *rz_hist)
+{
+    const int G = vec_grid, T = G * BLK;
+    double *z = (double *)malloc(((size_t)n + 1) * sizeof(double));
+    double *w = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *p = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *sv = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *part_a = (double *)calloc((size_t)sell_grid + 1, sizeof(double));
+    double *part_b = (double *)calloc((size_t)G, sizeof(double));
+    double *part_c = (double *)calloc((size_t)G, sizeof(double));
+    double *acc1 = (double *)malloc((size_t)T * sizeof(double)), *acc2 = (double *)malloc((size_t)T * sizeof(double));
+    const double tol2 = tol * tol;
+    memcpy(z, x, (size_t)n * sizeof(double));
+    spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, z, w, NULL);      /* A x0 */
+    for (int i = 0; i < T; ++i) acc1[i] = acc2[i] = 0.0;
+    for (int i = 0; i < n; ++i) {                                                              /* cg1_init_kernel */
+        const double b = r[i];
+        acc2[i % T] += b * b;
+        const double ri = b + (-1.0) * w[i];
+        r[i] = ri;
+        z[i] = precond ? ri * dinv[i] : ri;
+        acc1[i % T] += ri * z[i];
+    }
+    for (int b = 0; b < G; ++b) { part_b[b] = block_sum(acc1 + (size_t)b * BLK); part_c[b] = block_sum(acc2 + (size_t)b * BLK); }
+    double bb = 0.0, g_par[2] = {0.0, 0.0}, a_par[2] = {0.0, 0.0}, rz_last = 0.0;
+    int iters = 0, done = 0;
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    for (int k = 1; k <= limit; ++k) {
+        const int parity = k & 1, first = k == 1;
+        spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, z, w, part_a);   /* w = A z, delta partials */
+        const double gamma = reduce1(part_b, G);
+        const double delta = reduce1(part_a, sell_grid);
+        if (first) bb = reduce1(part_c, G);
+        const int go = fixed_iters > 0 ? 1 : (gamma / bb > tol2);
+        double beta = 0.0, alpha;
+        if (first) alpha = gamma / delta;
+        else {
+            beta = gamma / g_par[parity ^ 1];
+            alpha = gamma / (delta - beta * gamma / a_par[parity ^ 1]);
+        }
+        rz_last = gamma;
+        if (rz_hist) rz_hist[k - 1] = gamma;
+        if (!go) { done = 1; break; }
+        g_par[parity] = gamma;
+        a_par[parity] = alpha;
+        iters += 1;
+        const double na = -alpha;
+        for (int i = 0; i < T; ++i) acc1[i] = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double zi = z[i], wi = w[i];
+            const double pi = first ? zi : zi + beta * p[i];
+            const double si = first ? wi : wi + beta * sv[i];
+            p[i] = pi;
+            sv[i] = si;
+            x[i] = x[i] + alpha * pi;
+            const double ri = r[i] + na * si;
+            r[i] = ri;
+            const double zn = precond ? ri * dinv[i] : ri;
+            z[i] = zn;
+            acc1[i % T] += ri * zn;
+        }
+        for (int b = 0; b < G; ++b) part_b[b] = block_sum(acc1 + (size_t)b * BLK);
+    }
+    if (!done) {
+        rz_last = reduce1(part_b, G);                                                          /* cg_tail_kernel */
+        if (rz_hist) rz_hist[limit] = rz_last;
+    }
+    *bb_out = bb;
+    *rz_out = rz_last;
+    *done_out = done;
+    free(z); free(w); free(p); free(sv); free(part_a); free(part_b); free(part_c); free(acc1); free(acc2);
+    return iters;
+}
+
 /* y = A x in the row-per-lane kernel's order (for SpMV parity at bit level) */
 void orc_spmv_device_order(int n_tiles, const int *tile_first, const int *tile_rows, int sell_grid, const int *rp,
                            const int *col, const double *val, const double *x, double *y)
@@ -242,5 +329,228 @@ void orc_spmv_device_order(int n_tiles, const int *tile_first, const int *tile_r
     spmv_sell_order(n_tiles, tile_first, tile_rows, sell_grid, rp, col, val, x, y, NULL);
 }
 
-/* kept for later parts of this file (boundary-row pass): silence -Wunused */
-double orc_group_sum_probe(const double *v, int width) { return group_sum(v, width); }
+/* ====================================================================================================== */
+/* Building blocks for groups of ranks and for the split T operator: ONE rank's kernels each, in the device's   */
+/* order; the loop over iterations and ranks (halo exchange, rank-ordered sums of the all-reduce) is driven   */
+/* from kmcf_oracle.py (pcg_device_order_ranks).                                                               */
+/* ====================================================================================================== */
+
+typedef struct {
+    int n, n_short, n_halo;                       /* rows of this rank, rows before the long ones, halo slots        */
+    const int *rp, *col;                          /* CSR as stored: internal row order, halo columns = n + slot      */
+    const double *val;
+    int vec_grid;                                 /* blocks of the vector kernels                                    */
+    int sell_grid, n_tiles;                       /* row-per-lane kernel: blocks, tiles                              */
+    const int *tile_first, *tile_rows;
+    int boundary_grid, boundary_lpr, n_boundary;  /* separate pass over the short rows that touch the halo           */
+    const int *boundary_rows;
+    int n_long_items;                             /* long-row kernel: chunks (row, first entry, end entry, first chunk of the row) */
+    const int *long_items;
+    int sub_grid, sub_n;                          /* tunnel sub-block operator: blocks, local sub rows                */
+    const int *sub_rows;                          /* internal row of every local sub row                             */
+    const int *sub_rp, *sub_col;                  /* its CSR over the gathered sub-vector (ascending columns)        */
+    const double *sub_val;
+} orc_dev_plan;
+
+/* One distributed SpMV of one rank, y = A x with x = [own | halo] (+ S x_sub on the sub rows), every row and every
+ * p.Ap partial in the order of the kernel that computes it on the device (kmcf_spmv_device, csrc/kmcf_spmv.hip):
+ *   short rows without halo columns : spmv_sell_kernel (diagonal last; lanes of a tile; SKIP_BOUNDARY)
+ *   short rows with halo columns    : spmv_vec_kernel<LPR, ROW_LIST> (LPR strided partial sums + butterfly)
+ *   long rows                       : spmv_long_kernel (256-strided chunk sums, chunks added in order)
+ *   sub rows                        : sub_spmv_kernel (lane = column mod 64, groups ascending, butterfly; y += )
+ * *pap_local = reduce_partials over the four partial arrays (cg_finalize_kernel / the consumer's reduce). */
+void orc_dev_spmv(const orc_dev_plan *pl, const double *x, const double *xsub, double *y, int with_dot, double *pap_local)
+{
+    const int n = pl->n;
+    double *pa = (double *)calloc((size_t)pl->sell_grid + 1, sizeof(double));
+    double *pb = (double *)calloc((size_t)pl->boundary_grid + 1, sizeof(double));
+    double *pc = (double *)calloc(2, sizeof(double));
+    double *pd = (double *)calloc((size_t)pl->sub_grid + 1, sizeof(double));
+    /* ---- interior: row-per-lane kernel, rows that touch the halo skipped when this rank has a halo */
+    {
+        const int grid = pl->sell_grid, nb8 = grid >> 3, Cx = (pl->n_tiles + 7) >> 3;
+        for (int b = 0; b < grid; ++b) {
+            const int xcd = b & 7, bi = b >> 3;
+            int gmax = pl->n_tiles - xcd * Cx;
+            if (gmax > Cx) gmax = Cx;
+            const int nt = gmax > bi ? (gmax - bi + nb8 - 1) / nb8 : 0;
+            double dot[BLK];
+            for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+            for (int k = 0; k < nt; ++k) {
+                const int c = xcd * Cx + bi + k * nb8;
+                for (int t = 0; t < pl->tile_rows[c]; ++t) {
+                    const int row = pl->tile_first[c] + t;
+                    if (pl->n_halo > 0) {
+                        int isb = 0;
+                        for (int j = pl->rp[row]; j < pl->rp[row + 1]; ++j) isb |= pl->col[j] >= n;
+                        if (isb) continue;
+                    }
+                    const double sv = row_sum_diag_last(row, pl->rp, pl->col, pl->val, x);
+                    y[row] = sv;
+                    dot[t] += x[row] * sv;
+                }
+            }
+            pa[b] = block_sum(dot);
+        }
+    }
+    /* ---- boundary rows: spmv_vec_kernel<LPR, DOT, false, ROW_LIST> */
+    if (pl->n_halo > 0 && pl->n_boundary > 0) {
+        const int LPR = pl->boundary_lpr, RPB = BLK / LPR, grid = pl->boundary_grid;
+        const int G = (pl->n_boundary + RPB - 1) / RPB, Gx = (G + 7) >> 3, nb8 = grid >> 3;
+        for (int b = 0; b < grid; ++b) {
+            const int xcd = b & 7, bi = b >> 3;
+            double dot[BLK];
+            for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+            for (int g = bi; g < Gx; g += nb8) {
+                const int grp = xcd * Gx + g;
+                for (int rib = 0; rib < RPB; ++rib) {
+                    const int row = grp * RPB + rib;
+                    if (!(grp < G && row < pl->n_boundary)) continue;
+                    const int r = pl->boundary_rows[row];
+                    double lane[64];
+                    for (int l = 0; l < LPR; ++l) {
+                        double sv = 0.0;
+                        for (int j = pl->rp[r] + l; j < pl->rp[r + 1]; j += LPR) sv += pl->val[j] * x[pl->col[j]];
+                        lane[l] = sv;
+                    }
+                    const double sv = group_sum(lane, LPR);
+                    y[r] = sv;
+                    dot[rib * LPR] += x[r] * sv;
+                }
+            }
+            pb[b] = block_sum(dot);
+        }
+    }
+    /* ---- long rows: spmv_long_kernel */
+    if (pl->n_long_items > 0) {
+        const int ni = pl->n_long_items;
+        double *lpart = (double *)calloc((size_t)ni, sizeof(double));
+        for (int q = 0; q < ni; ++q) {
+            const int *it = pl->long_items + 4 * q;
+            double th[BLK];
+            for (int t = 0; t < BLK; ++t) {
+                double sv = 0.0;
+                for (int j = it[1] + t; j < it[2]; j += BLK) sv += pl->val[j] * x[pl->col[j]];
+                th[t] = sv;
+            }
+            lpart[q] = block_sum(th);
+        }
+        double dot[BLK];
+        for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+        for (int q = 0; q < ni; ++q) {
+            const int *a = pl->long_items + 4 * q;
+            if (a[3] != q) continue;
+            double tsum = 0.0;
+            for (int c = q; c < ni && pl->long_items[4 * c] == a[0]; ++c) tsum += lpart[c];
+            y[a[0]] = tsum;
+            dot[q % BLK] += x[a[0]] * tsum;
+        }
+        pc[0] = block_sum(dot);
+        free(lpart);
+    }
+    /* ---- sub-block: sub_spmv_kernel (a wave per local sub row; rows s = b 4 + w, + grid 4, ...) */
+    if (pl->sub_grid > 0 && pl->sub_n > 0) {
+        const int grid = pl->sub_grid;
+        for (int b = 0; b < grid; ++b) {
+            double dot[BLK];
+            for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int sr = b * 4 + wv; sr < pl->sub_n; sr += grid * 4) {
+                    double lane[64];
+                    for (int l = 0; l < 64; ++l) lane[l] = 0.0;
+                    for (int j = pl->sub_rp[sr]; j < pl->sub_rp[sr + 1]; ++j) {     /* ascending columns: per lane, ascending groups */
+                        const int cj = pl->sub_col[j];
+                        lane[cj & 63] += pl->sub_val[j] * xsub[cj];
+                    }
+                    const double acc = wave_sum64(lane);
+                    const int r = pl->sub_rows[sr];
+                    y[r] += acc;
+                    dot[wv * 64] += x[r] * acc;
+                }
+            pd[b] = block_sum(dot);
+        }
+    }
+    if (with_dot && pap_local) {
+        const double *pp[4] = {pa, pb, pc, pd};
+        const int nn[4] = {pl->sell_grid, pl->n_halo > 0 && pl->n_boundary > 0 ? pl->boundary_grid : 0, pl->n_long_items > 0 ? 1 : 0,
+                           pl->sub_grid};
+        *pap_local = reduce_partials(4, pp, nn);
+    }
+    free(pa); free(pb); free(pc); free(pd);
+}
+
+/* cg_init_kernel / cg1_init_kernel of one rank: r = b - A x0, z = r .* dinv; local sums of r.z and b.b */
+void orc_dev_init(int n, int vec_grid, double *r, const double *Ap, const double *dinv, int precond, double *z, double *rz_local,
+                  double *bb_local)
+{
+    const int G = vec_grid, T = G * BLK;
+    double *acc1 = (double *)calloc((size_t)T, sizeof(double)), *acc2 = (double *)calloc((size_t)T, sizeof(double));
+    double *p1 = (double *)calloc((size_t)G, sizeof(double)), *p2 = (double *)calloc((size_t)G, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        const double b = r[i];
+        acc2[i % T] += b * b;
+        const double ri = b + (-1.0) * Ap[i];
+        r[i] = ri;
+        z[i] = precond ? ri * dinv[i] : ri;
+        acc1[i % T] += ri * z[i];
+    }
+    for (int b = 0; b < G; ++b) { p1[b] = block_sum(acc1 + (size_t)b * BLK); p2[b] = block_sum(acc2 + (size_t)b * BLK); }
+    *rz_local = reduce1(p1, G);
+    *bb_local = reduce1(p2, G);
+    free(acc1); free(acc2); free(p1); free(p2);
+}
+
+/* cg_p_kernel of one rank (after the stopping test): x += xa p (pending), p = beta p + z, or p = z in the first iteration */
+void orc_dev_p(int n, double *p, const double *z, double *x, double beta, int first, int pending, double xa)
+{
+    for (int i = 0; i < n; ++i) {
+        if (first) { p[i] = z[i]; continue; }
+        if (pending) x[i] = x[i] + xa * p[i];
+        p[i] = beta * p[i] + z[i];
+    }
+}
+
+void orc_dev_x(int n, double *x, const double *p, double xa)
+{
+    for (int i = 0; i < n; ++i) x[i] = x[i] + xa * p[i];
+}
+
+/* cg_xr_kernel of one rank: r -= alpha Ap, z = r .* dinv, local r.z (pairs of rows per lane) */
+void orc_dev_xr(int n, int vec_grid, double *r, const double *Ap, const double *dinv, int precond, double alpha, double *z,
+                double *rz_local)
+{
+    const double na = -alpha;
+    double *part = (double *)calloc((size_t)vec_grid, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        r[i] = r[i] + na * Ap[i];
+        z[i] = precond ? r[i] * dinv[i] : r[i];
+    }
+    rz_partials_pairs(n, vec_grid, r, z, part);
+    *rz_local = reduce1(part, vec_grid);
+    free(part);
+}
+
+/* cg1_update_kernel of one rank */
+void orc_dev_cg1_update(int n, int vec_grid, double *x, double *r, double *p, double *sv, double *z, const double *w,
+                        const double *dinv, int precond, double alpha, double beta, int first, double *rz_local)
+{
+    const int G = vec_grid, T = G * BLK;
+    const double na = -alpha;
+    double *acc = (double *)calloc((size_t)T, sizeof(double)), *part = (double *)calloc((size_t)G, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        const double zi = z[i], wi = w[i];
+        const double pi = first ? zi : zi + beta * p[i];
+        const double si = first ? wi : wi + beta * sv[i];
+        p[i] = pi;
+        sv[i] = si;
+        x[i] = x[i] + alpha * pi;
+        const double ri = r[i] + na * si;
+        r[i] = ri;
+        const double zn = precond ? ri * dinv[i] : ri;
+        z[i] = zn;
+        acc[i % T] += ri * zn;
+    }
+    for (int b = 0; b < G; ++b) part[b] = block_sum(acc + (size_t)b * BLK);
+    *rz_local = reduce1(part, G);
+    free(acc); free(part);
+}

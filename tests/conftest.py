@@ -52,17 +52,23 @@ def ref5(oracle, dev5):
     return dict(ks=ks, neigh=nl, charge=charge, A=A, x=x, iters=it, relres=rel, tol=tol)
 
 
-# Iteration count of the cold K solve on the 5 nm device (x0 = 0, tolerance 1e-14 * N): the reference's own run logs
-# 327 (expected_output/output1_0.txt), the oracle (natural row order, sequential sums) 317-318.
-# The count moves by a few iterations with the order in which rows and partial sums are added (convergence is
-# decided at 1e-14): two correct implementations differ by 3 %.  Gate: within 2 % (BASELINE.md's figure) of the
-# interval those two span.
-REFERENCE_ITERS_5NM = 327
+# Iteration counts.  The cold K solve on the 5 nm device (x0 = 0, tolerance 1e-14 * N) takes 317-318 iterations in the
+# oracle's natural order (rows as given, pairwise dots), 327 in SURVEY.md's numpy restatement (BASELINE.md:31) and
+# 316 ... 328 across other summation orders: the count at which r.z / b.b crosses 1e-28 N^2 depends on the ORDER in
+# which the dot products' terms are added.  Counts are therefore compared only between runs that add in the SAME
+# order: the device against the oracle in the device's order (oracle/kmcf_oracle_order.c, fed by
+# kmcf_matrix_sum_plan), where they -- and every iterate -- must agree exactly.
 
 
-def iters_in_gate(got, oracle_iters, rel=0.02):
-    lo, hi = min(oracle_iters, REFERENCE_ITERS_5NM), max(oracle_iters, REFERENCE_ITERS_5NM)
-    return lo * (1.0 - rel) <= got <= hi * (1.0 + rel)
+def assert_solve_bit_identical(st, x_gpu, r_gpu, orc):
+    """st / x / r of a device solve against oracle.pcg_device_order(...) of the same system: identical."""
+    import numpy as np
+    assert st["iterations"] == orc["iterations"], (st["iterations"], orc["iterations"])
+    assert bool(st["converged"]) == bool(orc["converged"])
+    assert st["bb"] == orc["bb"] and st["rz"] == orc["rz"], (st["bb"], orc["bb"], st["rz"], orc["rz"])
+    assert np.array_equal(x_gpu, orc["x"]), float(np.abs(x_gpu - orc["x"]).max())
+    if r_gpu is not None:
+        assert np.array_equal(r_gpu, orc["r"]), float(np.abs(r_gpu - orc["r"]).max())
 
 
 # True residual ||b - A x|| / ||b|| of a converged K solve (5 nm device).  The loop stops on the RECURRENCE residual

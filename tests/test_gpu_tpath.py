@@ -4,8 +4,11 @@ split-operator Jacobi-PCG, I_macro, dissipated power) through the C ABI against 
 PARITY UNPINNED: no reference fixture covers this path (tests/test_oracle_T.py says what pins the oracle).
 Bars: integer work (atom list, both patterns, tunnel points) bit-exact; neighbour off-diagonals bit-exact,
 diagonals / preconditioner rtol 1e-13; WKB values rtol 1e-10 (device exp/pow against glibc's through an exponent
-of magnitude ~30); SpMV |dy| <= 1e-12 sum|a||x|; PCG at equal iteration count max|dx| <= 1e-9 |x|max; I_macro
-1e-9 relative; power 1e-8 of its maximum."""
+of magnitude ~30); SpMV |dy| <= 1e-12 sum|a||x|; I_macro 1e-9 relative; power 1e-8 of its maximum.
+Split PCG: against the oracle adding in the DEVICE's order on the system as assembled on the device
+(oracle/kmcf_oracle_order.c: row-per-lane, boundary-row, long-row and tunnel-block kernels, rank-ordered sums):
+iteration count and potentials IDENTICAL; against the oracle's natural order: iterates at 5 iterations 1e-10, the
+converged solution's TRUE residual <= 3 x the oracle's own true residual."""
 import threading
 
 import numpy as np
@@ -34,6 +37,24 @@ def _make(km, torch, xyz, element, charge, cb, metals, n1, layers, comm, nn_dist
     buf.site_CB_edge = torch.as_tensor(np.asarray(cb, np.float64), device="cuda")
     S.initialize_sparsity_T(buf, 0, nn_dist, n1, n1, layers, comm)
     return buf
+
+
+def _device_rank(km, oracle, buf, row0):
+    """What fixes one rank's summation order + the system as assembled on the device (for oracle.pcg_device_order_ranks)."""
+    S = km.solvers
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
+    plan, v, tn = mat.sum_plan(), S.t_vectors(buf), S.t_tunnel(buf)
+    ns = len(tn["row_ptr"]) - 1
+    sub = dict(grid=plan["sub_grid"], rows=tn["tunnel_idx"][tn["first"]:tn["first"] + ns] + 2 - row0, row_ptr=tn["row_ptr"],
+               col=tn["col"], val=tn["val"])
+    return dict(rank=oracle.DeviceRank(plan, sub), rhs=v["rhs"], dinv=v["dinv"], ns=ns, variant="cg1r" if plan["cg_variant"] else "classic")
+
+
+def _device_order_solve(oracle, parts, counts, displs, tol, max_it):
+    ns = np.array([p["ns"] for p in parts], np.int64)
+    return oracle.pcg_device_order_ranks([p["rank"] for p in parts], counts, displs, np.concatenate([p["rhs"] for p in parts]),
+                                         np.zeros(int(displs[-1] + counts[-1])), np.concatenate([p["dinv"] for p in parts]), tol,
+                                         max_it, variant=parts[0]["variant"], sub_counts=ns, sub_displs=np.cumsum(ns) - ns)
 
 
 def _compare_assembly(S, buf, T, r0=0, nr=None, s_first=None):
@@ -135,10 +156,14 @@ def test_small_device_single_rank(km, oracle, torch):
                                             1.0, cg_tolerance=1e-13, cg_max_iterations=20000, contact_x_lo=x_lo, contact_x_hi=x_hi)
     xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-13, 20000)
     assert st["converged"] == 1 and st["relres"] <= 1e-13
-    assert abs(st["iterations"] - ito) <= max(3, 0.05 * ito), (st["iterations"], ito)
+    od = _device_order_solve(oracle, [_device_rank(km, oracle, buf, 0)], [T.Nsub], [0], 1e-13, 20000)
+    assert st["iterations"] == od["iterations"], (st["iterations"], od["iterations"], ito)
+    np.testing.assert_array_equal(buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub], od["x"] * G0)
+    assert abs(st["iterations"] - ito) <= max(3, 0.05 * ito), (st["iterations"], ito)      # natural order: a nearby count
     v = buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub] / G0
     res = T.rhs - T.spmv(v)
-    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(T.rhs)
+    res_o = T.rhs - T.spmv(xo)
+    assert np.linalg.norm(res) <= 3 * np.linalg.norm(res_o), (np.linalg.norm(res), np.linalg.norm(res_o))
     tight = np.r_[0, 1, 2 + np.nonzero(np.isin(T.atom_element[:-1], [TI, N_EL]))[0]]
     assert np.abs(v[tight] - xo[tight]).max() <= 2e-6 * np.abs(xo).max()
     assert im > 0
@@ -210,14 +235,21 @@ def test_5nm_device(km, oracle, dev5, ref5, torch):
     im, st = S.update_power_gpu_sparse_dist(buf, *args, False, False, 1.0, cg_tolerance=1e-15 * T.N_atom, cg_max_iterations=2000)
     xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-15 * T.N_atom, 2000)
     # conductances from 1e7 (loop) to 1e-17 (far tunnel pairs): the Jacobi-PCG count moves with the summation
-    # order of the dots by ~10 % here (measured 349 in brick order on the GPU against 316 in natural order in the
-    # oracle; 2 % on the K system, whose span is 1e8) -- held to 15 %, the solution to the bars below
-    assert st["converged"] == 1 and abs(st["iterations"] - ito) <= 0.15 * ito, (st, ito)
-    print("T 5 nm: %d iterations (oracle %d), assembly %.3f ms, solve %.3f ms" % (st["iterations"], ito, st["ms_assembly"], st["ms_solve"]))
+    # order of the dots by ~10 % here (349 in the device's order against 316 in the oracle's natural order; 2 % on
+    # the K system, whose span is 1e8).  So the count is held to the oracle adding in the DEVICE's order: identical.
+    od = _device_order_solve(oracle, [_device_rank(km, oracle, buf, 0)], [T.Nsub], [0], 1e-15 * T.N_atom, 2000)
+    assert st["converged"] == 1 and st["iterations"] == od["iterations"], (st, od["iterations"], ito)
+    np.testing.assert_array_equal(buf.atom_virtual_potentials.cpu().numpy()[:T.Nsub], od["x"] * G0)
+    print("T 5 nm: %d iterations (oracle, device order: %d; natural order: %d), assembly %.3f ms, solve %.3f ms"
+          % (st["iterations"], od["iterations"], ito, st["ms_assembly"], st["ms_solve"]))
     v = buf.atom_virtual_potentials.cpu().numpy() / G0
     assert abs(v[1] - d["Vd"]) < 1e-3 and abs(v[NL] - d["Vd"]) < 0.1          # the reference's sanity check (:2014-2020)
-    res = T.rhs - T.spmv(v[:T.Nsub])
-    assert np.linalg.norm(res) / np.linalg.norm(T.rhs) <= 1e-6
+    # true residual: the recurrence stops at 2.6e-11; what rounding leaves between recurrence and true residual on a
+    # system spanning 1e7 ... 1e-17 is the oracle's to say: the device may not be more than 3 x worse
+    res = np.linalg.norm(T.rhs - T.spmv(v[:T.Nsub])) / np.linalg.norm(T.rhs)
+    res_o = np.linalg.norm(T.rhs - T.spmv(xo)) / np.linalg.norm(T.rhs)
+    print("T 5 nm: true residual %.3e (oracle, natural order: %.3e)" % (res, res_o))
+    assert res <= 3 * res_o, (res, res_o)
     assert im > 0
     buf.freeGPUmemory()
     comm.close()
@@ -254,7 +286,7 @@ def test_small_device_multirank(km, oracle, torch, P):
                                                     False, 1.0, cg_tolerance=1e-13, cg_max_iterations=20000, contact_x_lo=x_lo,
                                                     contact_x_hi=x_hi)
             out[r] = dict(im=im, st=st, v=buf.atom_virtual_potentials.cpu().numpy().copy(),
-                          pw=buf.site_power.cpu().numpy().copy())
+                          pw=buf.site_power.cpu().numpy().copy(), part=_device_rank(km, oracle, buf, r0), r0=r0, nr=nr)
             buf.freeGPUmemory()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -275,8 +307,15 @@ def test_small_device_multirank(km, oracle, torch, P):
     imo = T.imacro(m)
     pw = np.full(N, -7.0)
     T.power(m, 1.0, pw)
+    # the oracle adding in the device's order over the P ranks: identical count and potentials (heating on: the
+    # potentials were shifted by |min| after the scaling, current_solver_gpu.cu:2068-2071)
+    od = _device_order_solve(oracle, [o["part"] for o in out], [o["nr"] for o in out], [o["r0"] for o in out], 1e-13, 20000)
+    mo = od["x"] * G0
+    mo = mo + abs(min(mo[2:].min(), 0.0))        # (the minimum runs over N_atom + 2 entries: the last one is never solved, 0)
     for o in out:
-        assert o["st"]["converged"] == 1 and abs(o["st"]["iterations"] - ito) <= max(3, 0.05 * ito)
+        assert o["st"]["converged"] == 1 and o["st"]["iterations"] == od["iterations"], (o["st"]["iterations"], od["iterations"], ito)
+        np.testing.assert_array_equal(o["v"][:T.Nsub], mo)
+        assert abs(o["st"]["iterations"] - ito) <= max(3, 0.05 * ito)
         assert o["im"] > 0 and abs(o["im"] - out[0]["im"]) == 0
         np.testing.assert_array_equal(o["v"], out[0]["v"])             # replicated bit for bit
         np.testing.assert_array_equal(o["pw"], out[0]["pw"])

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline iterations (0 = auto, ~10-30 s)")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=5, help="timed solves of --steps iterations each; the line reports their median "
+                                                           "(the authors' protocol: median of 5 after warm-up, main_test_cg.cpp:209-211)")
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the beyond-cache SpMV measurement (roofline_hbm)")
     ap.add_argument("--diag-solves", type=int, default=0, help="after the timed region: time N more solves piecewise (stderr)")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "p2p", "p2p-only"],
                     help="multi-rank data path: auto = peer-to-peer windows if they come up, else RCCL; p2p-only = no RCCL at "
@@ -155,7 +158,11 @@ def main():
         pick = torch.tensor([1 if ("p2p" in ok and ok["p2p"] <= ok.get("rccl", 1e30)) else 0])
         dist.broadcast(pick, src=0)
         comm.select_transport(int(pick.item()))
-    elapsed, st = timed_solve(args.steps, args.warmup)
+    # K steps per solve, bracketed by barriers; `repeats` such solves, the median one is reported (all are listed)
+    runs = [timed_solve(args.steps, args.warmup if i == 0 else 0) for i in range(max(1, args.repeats))]
+    order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+    elapsed, st = runs[order[len(runs) // 2]]
+    all_ms = [round(r[0] * 1e3 / args.steps, 5) for r in runs]
     for _ in range(args.diag_solves):           # tuning aid: where a solve's wall time goes
         r, x, dinv = fresh_vectors()
         barrier()
@@ -239,6 +246,42 @@ def main():
             mat.replan()
             S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])      # the assembly writes the value codes again
 
+    # ---- the product kernel beyond the caches: the same row-per-lane coded SpMV on a synthetic crossbar of 12 x 12
+    # cells (3.6 M rows, ~350 MB of format: larger than the 256 MiB Infinity Cache), where its bytes really come from
+    # HBM.  Generated and measured here, after the timed region; this is the HBM fraction of the kernel `value` runs on.
+    roofline_hbm = None
+    if world == 1 and args.workload == "40nm" and not args.no_hbm_probe and minfo["spmv_coded"] == 2:
+        try:
+            d2 = km.structure.synth_crossbar_40nm(tiles=12)
+            NL2 = d2["N_contact"]
+            comm2 = S.KMC_comm(d2["N"] - 2 * NL2, d2["N"] + 1, d2["N"], d2["N"], rank=0, size=1, device=local_rank)
+            comm2.connect()
+            buf2 = S.GPUBuffers(d2["N"], d2["element"], d2["xyz"][:, 0], d2["xyz"][:, 1], d2["xyz"][:, 2], 52, d2["sigma"], d2["k"],
+                                d2["lattice"], d2["metals"], device=local_rank)
+            S.compute_neighbor_list(comm2, buf2, d2["nn_dist"], 52)
+            S.initialize_sparsity_K(buf2, d2["pbc"], d2["nn_dist"], NL2, comm2)
+            S.update_charge_gpu(buf2.site_element, buf2.site_charge, buf2.neigh_idx, buf2.N_, buf2.nn_, buf2.metal_types,
+                                buf2.num_metal_types_, comm2.counts_events, comm2.displs_events, comm2)
+            S.k_assemble(buf2, d2["Vd"], d2["high_G"], d2["low_G"])
+            mat2 = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf2.K_distributed))
+            i2 = mat2.info()
+            if i2["spmv_coded"] == 2:
+                mat2.spmv_bench(5, True)
+                us2 = mat2.spmv_bench(args.spmv_reps, True) * 1e3 / args.spmv_reps
+                n2 = i2["rows_this_rank"]
+                b2 = 2.0 * i2["spmv_stream_entries"] + 4.0 * i2["spmv_window_cols"] + 28.0 * n2 + 48.0 * i2["spmv_tiles"]
+                a2 = b2 / (us2 * 1e-6) / 1e9
+                roofline_hbm = {"bound": "hbm", "kernel": kname, "workload": d2["name"], "rows": n2, "nnz": int(i2["nnz"]),
+                                "us_per_launch": round(us2, 2), "algorithmic_bytes_per_launch": int(b2),
+                                "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                "traffic": None, "working_set_bytes": int(b2 + 16.0 * n2),
+                                "fits_infinity_cache": bool(b2 + 16.0 * n2 < mall),
+                                "csr_equivalent_bytes": int(12.0 * i2["nnz"] + 20.0 * n2)}
+            buf2.freeGPUmemory()
+            comm2.close()
+        except Exception as e:                      # a diagnostic block must not cost the line
+            roofline_hbm = {"error": str(e)[:200]}
+
     # multi-rank diagnostic: the pieces of one distributed iteration timed separately (rank 0's clock), on every
     # transport that is up
     diag = None
@@ -271,11 +314,11 @@ def main():
     if world == 1 and os.path.exists(tpath):
         tj = json.load(open(tpath))
         entries = tj["kernels"] if "kernels" in tj else [tj]
-        for blk in (roofline, roofline_csr):
-            if blk is None:
+        for blk in (roofline, roofline_csr, roofline_hbm):
+            if blk is None or "kernel" not in blk:
                 continue
             for e in entries:
-                if e.get("rows") == n_loc and e.get("workload") == d["name"] and \
+                if e.get("rows") == blk.get("rows", n_loc) and e.get("workload") == blk.get("workload", d["name"]) and \
                         e.get("kernel", "").split("<")[0] == blk["kernel"].split(" ")[0]:
                     blk["traffic"] = e["corrected_bytes_per_launch"]
                     blk["traffic_source"] = e.get("source", "profiles/spmv_traffic.json")
@@ -298,7 +341,24 @@ def main():
         tc = time.perf_counter()
         O.pcg_jacobi_omp(rp, col, vec["val"], vec["rhs"], np.zeros(n_loc), vec["dinv"], tol, 10 ** 9, fixed_iters=n_it)
         tc = time.perf_counter() - tc
-        cpu = {"value": round(n_it / tc, 2), "unit": "iterations/s", "cores": O.omp_threads(), "kind": "port",
+        cores = O.omp_threads()
+        # the same on ONE thread (SURVEY 8d asks for both), a few seconds
+        O.set_threads(1)
+        n1 = int(max(3, min(2000, 4.0 / max(t5 * cores * 0.6, 1e-6))))
+        t1 = time.perf_counter()
+        O.pcg_jacobi_omp(rp, col, vec["val"], vec["rhs"], np.zeros(n_loc), vec["dinv"], tol, 10 ** 9, fixed_iters=n1)
+        t1 = time.perf_counter() - t1
+        model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        cpu = {"value": round(n_it / tc, 2), "unit": "iterations/s", "cores": cores, "kind": "port",
+               "cpu_model": model, "host_cores_visible": os.cpu_count(),
+               "one_thread": {"value": round(n1 / t1, 2), "unit": "iterations/s", "sample": "%d iterations, %.1f s" % (n1, t1)},
                "sample": "%d fixed PCG iterations of the same matrix (oracle/kmcf_oracle.c orc_pcg_jacobi_omp, "
                          "OpenMP, %.1f s)" % (n_it, tc)}
 
@@ -307,6 +367,7 @@ def main():
             "metric": "cg_iterations_per_sec", "value": round(args.steps / elapsed, 2), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 5), "higher_is_better": True,
+            "repeats": len(runs), "ms_per_step_all": all_ms, "ms_per_step_min": min(all_ms), "ms_per_step_max": max(all_ms),
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": d["name"], "rows": n_if, "nnz": nnz_tot, "sites": d["N"],
                        "partition": "1-D block rows x %d" % world, "transport": comm.transport(), "solver": "jacobi-pcg fixed %d iterations" % args.steps,
@@ -314,6 +375,7 @@ def main():
                        "setup_s": round(t_setup, 2), "device_ms_cg": round(st["ms_solve"], 3)},
             "roofline": roofline,
             "roofline_csr": roofline_csr,
+            "roofline_hbm": roofline_hbm,
             "cpu_baseline": cpu,
         }
         if diag is not None:

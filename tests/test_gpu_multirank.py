@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(km, d, P, ref_charge, expect_transport="loopback"):
+def _run_ranks(km, d, P, ref_charge, expect_transport="loopback", slow_rank=None):
     import torch
     S = km.solvers
     NL = d["N_contact"]
@@ -47,6 +47,9 @@ def _run_ranks(km, d, P, ref_charge, expect_transport="loopback"):
             p = torch.as_tensor(xg[r0:r0 + nr].copy(), device="cuda")
             Ap = torch.empty_like(p)
             mat.spmv(p, Ap)
+            if slow_rank == r:
+                import time
+                time.sleep(1.5)              # this rank arrives late at the solve's first exchanges (see the slow-rank test)
             st = S.background_potential_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"],
                                                    d["nn_dist"], len(d["metals"]), 0)
             plan, kv = mat.sum_plan(), S.k_vectors(buf)      # what fixes this rank's summation order; the system as assembled
@@ -244,3 +247,22 @@ def test_multirank_generic_matrix_small_and_empty_ranks(km, n, P):
         np.testing.assert_allclose(o["Ap"], y[o["r0"]:o["r0"] + o["nr"]], rtol=1e-13, atol=1e-13)
         assert o["st"]["converged"] == 1 and o["st"]["iterations"] == out[0]["st"]["iterations"]
     assert np.abs(M @ sol - b).max() <= 1e-9
+
+
+def test_p2p_slow_rank_cannot_have_its_halo_overwritten(km, oracle, dev5, ref5, monkeypatch):
+    """A solve starts with TWO SpMVs and no all-reduce between them (A x0, then A z of the single-reduction loop): with
+    three ranks that are all neighbours of each other (the 5 nm device's site order), a fast rank reaches its second
+    put while a neighbour still waits for the late third rank's first one.  The landing zones are double-buffered by
+    sequence parity and a put waits for the acknowledgement of the put before last (csrc/kmcf_p2p.hip), so the late
+    rank changes nothing: bit-identical to the host-synchronous loopback transport."""
+    monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
+    monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
+    monkeypatch.delenv("KMCF_TRANSPORT", raising=False)
+    base = _run_ranks(km, dev5, 3, ref5["charge"])
+    monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+    monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
+    for slow in (2, 0):
+        p2p = _run_ranks(km, dev5, 3, ref5["charge"], expect_transport="p2p (in-process group)", slow_rank=slow)
+        for a, b in zip(base, p2p):
+            assert a["st"]["iterations"] == b["st"]["iterations"] and a["st"]["rz"] == b["st"]["rz"]
+            assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["Ap"], b["Ap"])

@@ -19,7 +19,7 @@
 #include <chrono>
 #include <cmath>
 
-#include "kmcf_internal.hpp"
+#include "kmcf_p2p_dev.hpp"
 
 namespace {
 
@@ -341,6 +341,10 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
         KMCF_HIP(hipGetLastError());
         KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 2));
     }
+    // "direct" peer-to-peer protocol: halo sequence numbers are counted per launch below and set back to per executed
+    // SpMV after the loop (see pcg1_loop)
+    const bool direct = multi && c->nranks > 1 && kmcf_p2p_direct(m);
+    const u64 halo0 = direct ? *kmcf_p2p_halo_seq(m, 0) : 0;
 
     int launched = 0;
     bool done = false;
@@ -377,6 +381,10 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
             KMCF_HIP(hipStreamSynchronize(st));
             done = c->h_pinned[0] != 0;
         }
+    }
+    if (direct) {       // one SpMV (put, consumption, acknowledgement) per iteration that went on
+        const u64 executed = done ? (u64)c->h_pinned[1] : (u64)launched;
+        *kmcf_p2p_halo_seq(m, 0) = *kmcf_p2p_halo_seq(m, 1) = halo0 + executed;
     }
     // the loop condition is evaluated once more after the last iteration (:217): it
     // decides `converged` and provides the printed residual (:273)
@@ -476,6 +484,110 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
     if (threadIdx.x == 0) part_rz[blockIdx.x] = t;
 }
 
+
+// The same update with the group's exchanges folded in ("direct" peer-to-peer protocol, kmcf_p2p_dev.hpp): ONE kernel
+// per iteration besides the SpMV's two.
+//   * all-reduce: every block forms this rank's sums of gamma, delta (and b.b) from the partial arrays; block 0 stores
+//     them into slot [parity][rank] of every peer's window and raises its flag there; every block waits (bounded)
+//     for the P flags of its OWN window and adds the P slots in rank order -- the same numbers in the same order on
+//     every rank and in every block;
+//   * acknowledgement of the halo the SpMV in front of this kernel has consumed (block 0);
+//   * put: the thread that computes the new z of a row a neighbour needs stores it into buffer (seq_put & 1) of that
+//     neighbour's landing zone (after the acknowledgements of seq_put - 2 are in: every block checks); the last block
+//     to finish raises the neighbours' flags -- the halo of the NEXT SpMV is on its way while this kernel still runs.
+// Arithmetic and summation order are cg1_update_kernel's (the loopback transport runs that one: iterates bit-identical).
+template <bool PRECOND>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_p2p_kernel(
+    int n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p, double *__restrict__ s,
+    double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta,
+    part_ref pbb, kmcf_scalars *__restrict__ S, int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz,
+    kmcf_p2p_dev pd, u64 seq_red, u64 seq_ack, u64 seq_put)
+{
+    __shared__ double lds4[4];
+    __shared__ double red[4];
+    __shared__ int s_last;
+    if (S->done) return;
+    const int t = threadIdx.x, rpar = (int)(seq_red & 1);
+    const double g_loc = reduce_partials(pgamma, lds4);
+    const double d_loc = reduce_partials(pdelta, lds4);
+    const double b_loc = first ? reduce_partials(pbb, lds4) : 0.0;
+    if (blockIdx.x == 0) {
+        if (t < pd.P) {
+            double *slot = reinterpret_cast<double *>(pd.peer[t] + P2P_OFF_RED_SLOT) + ((size_t)rpar * P2P_MAXR + pd.rank) * 4;
+            store_system(&slot[0], g_loc);
+            store_system(&slot[1], d_loc);
+            store_system(&slot[2], b_loc);
+            store_release_system(reinterpret_cast<u64 *>(pd.peer[t] + P2P_OFF_RED_FLAG) + (size_t)rpar * P2P_MAXR + pd.rank, seq_red);
+        } else if (t >= 64 && t < 64 + pd.n_nb) {
+            store_release_system(pd.ack_ptr[t - 64], seq_ack);
+        }
+    }
+    if (t < pd.P)
+        wait_ge(reinterpret_cast<const u64 *>(pd.peer[pd.rank] + P2P_OFF_RED_FLAG) + (size_t)rpar * P2P_MAXR + t, seq_red, pd.timeout, pd.d_err,
+                pd.h_err, 1);
+    else if (t >= 64 && t < 64 + pd.n_nb && seq_put > 2)
+        wait_ge(&pd.acks[t - 64], seq_put - 2, pd.timeout, pd.d_err, pd.h_err, 5);
+    __syncthreads();
+    if (__hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (t < 3) {
+        const double *slots = reinterpret_cast<const double *>(pd.peer[pd.rank] + P2P_OFF_RED_SLOT) + (size_t)rpar * P2P_MAXR * 4;
+        double v = 0.0;
+        for (int q = 0; q < pd.P; ++q) v += load_system(&slots[(size_t)q * 4 + t]);      // rank order on every rank
+        red[t] = v;
+    }
+    __syncthreads();
+    const double gamma = red[0], delta = red[1];
+    const double bb = first ? red[2] : S->bb;
+    const bool go = check_tol ? (gamma / bb > tol2) : true;
+    double beta = 0.0, alpha;
+    if (first) {
+        alpha = gamma / delta;
+    } else {
+        beta = gamma / S->rz[parity ^ 1];
+        alpha = gamma / (delta - beta * gamma / S->alpha[parity ^ 1]);
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        S->rz_last = gamma;
+        S->red[0] = gamma; S->red[1] = delta; S->red[2] = first ? red[2] : 0.0;
+        if (first) S->bb = bb;
+        if (go) { S->rz[parity] = gamma; S->alpha[parity] = alpha; S->pAp = delta; S->iters += 1; }
+        else S->done = 1;
+    }
+    if (!go) return;
+    const double na = -alpha;
+    const long long ppar = (long long)(seq_put & 1);
+    double rz = 0.0;
+    for (int i = blockIdx.x * KMCF_BLOCK + t; i < n; i += gridDim.x * KMCF_BLOCK) {
+        const double zi = z[i], wi = w[i];
+        const double pi = first ? zi : zi + beta * p[i];
+        const double si = first ? wi : wi + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] = x[i] + alpha * pi;
+        const double ri = r[i] + na * si;
+        r[i] = ri;
+        const double zn = PRECOND ? ri * dinv[i] : ri;
+        z[i] = zn;
+        rz += ri * zn;
+        const int b = pd.put_row[i];
+        if (b >= 0)
+            for (int e = pd.putr_ptr[b]; e < pd.putr_ptr[b + 1]; ++e) store_system(pd.putr_addr[e] + ppar * pd.putr_stride[e], zn);
+    }
+    const double tsum = block_sum(rz, lds4);
+    if (t == 0) part_rz[blockIdx.x] = tsum;
+    // the last block to finish raises the neighbours' flags
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(pd.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (t < pd.n_nb) store_release_system(pd.put_flag[t], seq_put);
+    if (t == 0) __hip_atomic_store(pd.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 1-block finalize for the multi-rank case: red[0] = gamma, red[1] = delta, red[2] = bb partial (first only)
 __global__ __launch_bounds__(KMCF_BLOCK) void cg1_finalize_kernel(part_ref pg, part_ref pd, part_ref pb, int first,
                                                                   kmcf_scalars *__restrict__ S)
@@ -517,6 +629,12 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
     KMCF_TRY(kmcf_spmv_device(m, false, false));                       // A x0
     cg1_init_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_r, m->d_Ap, m->d_dinv, m->d_p, m->d_part_b, m->d_part_c);
     KMCF_HIP(hipGetLastError());
+    // "direct" peer-to-peer protocol: the exchanges ride in the update kernel (cg1_update_p2p_kernel).  Sequence numbers
+    // are counted per LAUNCH here and set back to per EXECUTED exchange after the loop (kernels behind the stop return
+    // at once, on every rank alike): the protocol's parities and acknowledgement windows need dense numbers.
+    const bool fused = multi && c->nranks > 1 && kmcf_p2p_direct(m);
+    const bool p2p_red = multi && c->nranks > 1 && c->p2p_active;
+    const u64 red0 = p2p_red ? kmcf_p2p_red_seq(c) : 0, halo0 = fused ? *kmcf_p2p_halo_seq(m, 0) : 0;
 
     int launched = 0;
     bool done = false;
@@ -528,7 +646,16 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
         for (int i = 0; i < chunk; ++i) {
             const int k = launched + i + 1;
             const int parity = k & 1, first = (k == 1) ? 1 : 0;
-            KMCF_TRY(kmcf_spmv_device(m, true, true));                 // w = A z, delta partials
+            KMCF_TRY(kmcf_spmv_device(m, true, true, fused ? 1 : 0));  // w = A z, delta partials
+            if (fused) {
+                const u64 sr = kmcf_p2p_next_red_seq(c), sh = *kmcf_p2p_halo_seq(m, 0);
+                cg1_update_p2p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
+                                                                          pg_loc, pd_loc, pb_loc, S, parity, first, tol2, check_tol,
+                                                                          m->d_part_b, kmcf_p2p_dev_of(m), sr, sh, sh + 1);
+                KMCF_HIP(hipGetLastError());
+                *kmcf_p2p_halo_seq(m, 1) = sh + 1;                      // the halo of the next SpMV is put
+                continue;
+            }
             if (multi && c->p2p_active && c->nranks > 1) {
                 // finalize + exchange in one 1-block kernel (the b.b partials only count in the first iteration:
                 // later ones re-send stale ones, which nobody reads)
@@ -551,6 +678,22 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             KMCF_HIP(hipStreamSynchronize(st));
             done = c->h_pinned[0] != 0;
+        }
+    }
+    if (p2p_red && !fused) kmcf_p2p_set_red_seq(c, red0 + (done ? (u64)c->h_pinned[1] + 1 : (u64)launched));   // (skipped ones: no number)
+    if (fused) {
+        // exchanges that really ran: one all-reduce, one consumed halo and one acknowledgement per executed update kernel
+        // (iterations that went on + the one that stopped); a put by every update that went on + the stand-alone first
+        const u64 executed = done ? (u64)c->h_pinned[1] + 1 : (u64)launched;
+        kmcf_p2p_set_red_seq(c, red0 + executed);
+        u64 &hs = *kmcf_p2p_halo_seq(m, 0), &hp = *kmcf_p2p_halo_seq(m, 1);
+        hs = halo0 + executed;
+        hp = done ? hs : hs + 1;
+        if (hp > hs) {
+            // the loop ended on its iteration limit: the last update has put a halo no SpMV will read.  Consumed
+            // unread: acknowledged, so that the sequence stays dense (every rank does the same)
+            ++hs;
+            KMCF_TRY(kmcf_p2p_direct_ack(m, hs, false));
         }
     }
     if (!done) {   // r.z after the last iteration, for the printed residual

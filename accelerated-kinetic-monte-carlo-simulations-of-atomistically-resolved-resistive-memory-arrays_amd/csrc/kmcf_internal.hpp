@@ -154,6 +154,7 @@ struct kmcf_matrix {
     double *d_val = nullptr;
     int *d_boundary_rows = nullptr;    // list of local rows touching the halo
     unsigned char *d_is_boundary = nullptr;  // per-row flag (nullptr if no halo)
+    int *d_build_tab = nullptr;        // exchange table of the build (freed with the matrix)
     int *d_send_idx = nullptr;         // concatenated rows_per_neighbour[k>=1]
     double *d_send_buf = nullptr;
     int *d_halo_gid = nullptr;         // global column id of each halo slot
@@ -308,7 +309,8 @@ struct kmcf_subop {
 // spmv.hip
 int kmcf_spmv_plan(kmcf_matrix *m);
 // Ap = A*p on m->d_p (already holding local p), writes m->d_Ap and pAp partials.
-int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done);
+// flags bit 0 ("direct" peer-to-peer protocol only): the caller's NEXT kernel acknowledges this SpMV's halo
+int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags = 0);
 // up to four arrays of per-block partial sums (an SpMV writes one per pass: interior rows, boundary rows, long
 // rows, sub-block), added in a fixed order by whoever consumes them
 struct kmcf_part4 { const double *p[4]; int n[4]; };
@@ -351,6 +353,10 @@ int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land
                             const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo);
 void kmcf_p2p_matrix_free(kmcf_matrix *m);
 int kmcf_p2p_halo_exchange(kmcf_matrix *m);
+// "direct" protocol (kmcf_p2p_dev.hpp): usable for this matrix?  (group on the p2p transport, per-row put table built)
+bool kmcf_p2p_direct(const kmcf_matrix *m);
+int kmcf_p2p_direct_put(kmcf_matrix *m, unsigned long long seq, bool skip_if_done);      // standalone put of d_p's sent rows (compute stream)
+int kmcf_p2p_direct_ack(kmcf_matrix *m, unsigned long long seq, bool skip_if_done);      // standalone acknowledgement (compute stream)
 // matrix.hip
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
                       const int *h_row_ptr, const int *h_col_global, const double *h_val,

@@ -333,13 +333,14 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
             tab[(size_t)W * rank + 4 * P + q] = ack8 + (k - 1);                  // q acknowledges MY puts here
             tab[(size_t)W * rank + 5 * P + q] = std::max(m->n_halo, 1);
         }
-        int *d_tab = nullptr;
+        // (kept until the matrix is destroyed: hipFree waits for EVERY stream of the process, and in an in-process group
+        // another rank's kernel may already be waiting, on the device, for this rank's next exchange)
+        int *&d_tab = m->d_build_tab;
         KMCF_TRY(dev_upload(&d_tab, tab));
         int rc = kmcf_comm_allgatherv_int(c, d_tab, cnt.data(), dsp.data());
         if (rc == KMCF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KMCF_ERR_HIP;
         if (rc == KMCF_OK && c->p2p_active) rc = kmcf_p2p_check(c);
         if (rc == KMCF_OK && hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = KMCF_ERR_HIP;
-        hipFree(d_tab);
         if (rc != KMCF_OK) return rc;
         for (int a = 0; a < P; ++a)
             for (int b = 0; b < P; ++b)
@@ -429,7 +430,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,
                         m->d_tile, m->d_wcol, m->d_idx16, m->d_dict, m->d_diagv, m->d_diag_pos, m->d_code_fail,
-                        m->d_long_items, m->d_long_part, m->d_long_ctr, m->d_tile4, m->d_tbase};
+                        m->d_long_items, m->d_long_part, m->d_long_ctr, m->d_tile4, m->d_tbase, m->d_build_tab};
         for (void *p : ptrs)
             if (p) hipFree(p);
     }

@@ -30,70 +30,9 @@
 // GPU, where RCCL refuses to run).  Members of an in-process loopback group exchange plain pointers.
 #include <cstring>
 
-#include "kmcf_internal.hpp"
-
-constexpr int P2P_MAXR = 64;
-constexpr size_t P2P_OFF_RED_SLOT = 0;       // double [2][MAXR][4]
-constexpr size_t P2P_OFF_RED_FLAG = 4096;    // u64    [2][MAXR]
-constexpr size_t P2P_OFF_G_FLAG = 5120;      // u64    [MAXR]   published gather sequence of rank q (written by q)
-constexpr size_t P2P_OFF_G_ACK = 5632;       // u64    [MAXR]   gather sequence rank q has consumed from me
-constexpr size_t P2P_OFF_BUMP = 8192;
-
-typedef unsigned long long u64;
-
-struct kmcf_p2p {
-    int nranks = 1, rank = 0;
-    char *win = nullptr;
-    size_t win_bytes = 0;
-    bool fine_grained = false;
-    std::vector<char *> peer;                // base of every rank's window in this address space
-    std::vector<bool> ipc_opened;
-    char **d_peer = nullptr;
-    size_t stage_off = 0, stage_half = 0;    // two halves of gather staging
-    size_t bump = 0;
-    u64 seq_red = 0, seq_gather = 0;
-    long long timeout_ticks = 0;             // wall_clock64 ticks (hipDeviceAttributeWallClockRate)
-    int *d_err = nullptr;                    // device copy of the error word (polled by waiting kernels)
-    int *h_err = nullptr;                    // pinned host copy (read by the host after a synchronisation)
-    unsigned int *d_ctr = nullptr;           // last-block counters: [0] gather stage, [1] gather pull
-};
-
-// per-matrix state of the halo protocol
-struct kmcf_p2p_halo {
-    double **d_put_ptr = nullptr;            // remote address of every packed entry (buffer 0 of the receiver's landing zone)
-    long long *d_put_stride = nullptr;       // per packed entry: doubles from buffer 0 to buffer 1 there (the receiver's halo size)
-    u64 **d_put_flag = nullptr;              // remote flag per neighbour (k >= 1)
-    u64 **d_ack_ptr = nullptr;               // per neighbour: where I acknowledge ITS puts (in its window)
-    size_t land_off = 0, flag_off = 0;       // own landing zone (2 x n_halo doubles) and flags (nnb - 1) in my window
-    size_t ack_off = 0;                      // acknowledgements of MY puts, written by the neighbours (nnb - 1) in my window
-    u64 seq = 0;
-    unsigned int *d_ctr = nullptr;           // [0] put: last block raises the flags; [1] wait: last block acknowledges
-};
+#include "kmcf_p2p_dev.hpp"
 
 namespace {
-
-__device__ __forceinline__ void store_release_system(u64 *p, u64 v)
-{
-    __threadfence_system();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the fence's write-back must have drained before the flag goes out
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// bounded wait for *p >= v.  err codes: 1 all-reduce, 2 halo, 3 gather flag, 4 gather ack
-__device__ __forceinline__ bool wait_ge(const u64 *p, u64 v, long long timeout, int *d_err, int *h_err, int code)
-{
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
-        if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // already failed
-        if (wall_clock64() - t0 > timeout) {
-            __hip_atomic_store(d_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(h_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return true;
-}
 
 // One block.  buf[0..count): my partials in, the sums over all ranks out.
 __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_kernel(char *const *__restrict__ peer, int P, int rank, double *__restrict__ buf,
@@ -166,9 +105,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_put_kernel(int n_send, const i
                                                              double *const *__restrict__ put_ptr, const long long *__restrict__ put_stride,
                                                              int n_nb, u64 *const *__restrict__ put_flag, const u64 *__restrict__ acks,
                                                              u64 seq, long long timeout, int *d_err, int *h_err,
-                                                             unsigned int *__restrict__ ctr)
+                                                             unsigned int *__restrict__ ctr, const kmcf_scalars *__restrict__ S, int check_done)
 {
     __shared__ int s_last;
+    if (check_done && S->done) return;
     if ((int)threadIdx.x < n_nb && seq > 2) wait_ge(&acks[threadIdx.x], seq - 2, timeout, d_err, h_err, 5);
     __syncthreads();
     const long long par = (long long)(seq & 1);
@@ -208,6 +148,14 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_halo_wait_kernel(int n_nb, con
     if (!s_last) return;
     if ((int)threadIdx.x < n_nb) store_release_system(ack_ptr[threadIdx.x], seq);
     if (threadIdx.x == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acknowledgement alone (direct protocol: an SpMV whose successor kernel does not acknowledge)
+__global__ __launch_bounds__(64) void p2p_ack_kernel(int n_nb, u64 *const *__restrict__ ack_ptr, u64 seq, const kmcf_scalars *__restrict__ S,
+                                                    int check_done)
+{
+    if (check_done && S->done) return;
+    if ((int)threadIdx.x < n_nb) store_release_system(ack_ptr[threadIdx.x], seq);
 }
 
 // gather, step 1: my slice into my staging half (after every peer has consumed what was there two gathers ago),
@@ -502,6 +450,88 @@ int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land
     KMCF_HIP(hipMemcpy(h->d_put_stride, stride.data(), stride.size() * sizeof(long long), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(h->d_put_flag, flg.data(), flg.size() * sizeof(u64 *), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(h->d_ack_ptr, ack.data(), ack.size() * sizeof(u64 *), hipMemcpyHostToDevice));
+    // the same entries by internal row: the kernel that computes a row puts it (direct protocol)
+    {
+        const int n = m->n_loc;
+        std::vector<int> inv((size_t)std::max(n, 1), 0);
+        for (int i = 0; i < n; ++i) inv[m->h_perm.empty() ? i : m->h_perm[i]] = i;
+        std::vector<std::vector<int>> per_row((size_t)std::max(n, 1));        // entries (index into put / stride) of every internal row
+        for (int k = 1; k < nnb; ++k)
+            for (size_t i = 0; i < m->rows_per_neighbour[k].size(); ++i)
+                per_row[(size_t)inv[m->rows_per_neighbour[k][i]]].push_back(m->send_offset[k] + (int)i);
+        std::vector<int> put_row((size_t)std::max(n, 1), -1), rptr(1, 0);
+        std::vector<double *> raddr;
+        std::vector<long long> rstride;
+        for (int i = 0; i < n; ++i) {
+            if (per_row[i].empty()) continue;
+            put_row[i] = (int)rptr.size() - 1;
+            for (int e : per_row[i]) { raddr.push_back(put[(size_t)e]); rstride.push_back(stride[(size_t)e]); }
+            rptr.push_back((int)raddr.size());
+        }
+        if (raddr.empty()) { raddr.push_back(nullptr); rstride.push_back(0); }
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_put_row), put_row.size() * sizeof(int)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_ptr), rptr.size() * sizeof(int)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_addr), raddr.size() * sizeof(double *)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_stride), rstride.size() * sizeof(long long)));
+        KMCF_HIP(hipMemcpy(h->d_put_row, put_row.data(), put_row.size() * sizeof(int), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(h->d_putr_ptr, rptr.data(), rptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(h->d_putr_addr, raddr.data(), raddr.size() * sizeof(double *), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(h->d_putr_stride, rstride.data(), rstride.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    return KMCF_OK;
+}
+
+bool kmcf_p2p_direct(const kmcf_matrix *m)
+{
+    static const bool off = getenv("KMCF_P2P_DIRECT") && atoi(getenv("KMCF_P2P_DIRECT")) == 0;
+    const kmcf_comm *c = m->comm;
+    // long rows and the tunnel sub-block read the halo behind p_local: they keep the copying protocol
+    return !off && c->p2p_active && c->nranks > 1 && m->p2p && m->p2p->d_put_row && m->n_long_items == 0 && !m->sub;
+}
+
+kmcf_p2p_dev kmcf_p2p_dev_of(const kmcf_matrix *m)
+{
+    const kmcf_p2p *w = m->comm->p2p;
+    const kmcf_p2p_halo *h = m->p2p;
+    kmcf_p2p_dev d;
+    d.peer = w->d_peer; d.P = m->comm->nranks; d.rank = m->comm->rank; d.timeout = w->timeout_ticks; d.d_err = w->d_err; d.h_err = w->h_err;
+    d.n_nb = m->number_of_neighbours - 1;
+    d.flags = reinterpret_cast<const u64 *>(w->win + h->flag_off);
+    d.acks = reinterpret_cast<const u64 *>(w->win + h->ack_off);
+    d.ack_ptr = h->d_ack_ptr; d.put_flag = h->d_put_flag;
+    d.landing = reinterpret_cast<const double *>(w->win + h->land_off);
+    d.n_halo = std::max(m->n_halo, 1);
+    d.put_row = h->d_put_row; d.putr_ptr = h->d_putr_ptr; d.putr_addr = h->d_putr_addr; d.putr_stride = h->d_putr_stride;
+    d.ctr = h->d_ctr;
+    return d;
+}
+
+unsigned long long kmcf_p2p_next_red_seq(kmcf_comm *c) { return ++c->p2p->seq_red; }
+unsigned long long kmcf_p2p_red_seq(const kmcf_comm *c) { return c->p2p->seq_red; }
+void kmcf_p2p_set_red_seq(kmcf_comm *c, unsigned long long v) { c->p2p->seq_red = v; }
+unsigned long long *kmcf_p2p_halo_seq(kmcf_matrix *m, int which) { return which ? &m->p2p->seq_put : &m->p2p->seq; }
+
+int kmcf_p2p_direct_put(kmcf_matrix *m, unsigned long long seq, bool skip_if_done)
+{
+    kmcf_comm *c = m->comm;
+    kmcf_p2p *w = c->p2p;
+    kmcf_p2p_halo *h = m->p2p;
+    const int n_nb = m->number_of_neighbours - 1;
+    if (n_nb <= 0) return KMCF_OK;
+    const int g = std::max(1, std::min((m->n_send + KMCF_BLOCK - 1) / KMCF_BLOCK, 64));
+    p2p_put_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(m->n_send, m->d_send_idx, m->d_p, h->d_put_ptr, h->d_put_stride, n_nb, h->d_put_flag,
+                                                    reinterpret_cast<const u64 *>(w->win + h->ack_off), seq, w->timeout_ticks, w->d_err, w->h_err,
+                                                    h->d_ctr, m->d_S, skip_if_done ? 1 : 0);
+    KMCF_HIP(hipGetLastError());
+    return KMCF_OK;
+}
+
+int kmcf_p2p_direct_ack(kmcf_matrix *m, unsigned long long seq, bool skip_if_done)
+{
+    const int n_nb = m->number_of_neighbours - 1;
+    if (n_nb <= 0) return KMCF_OK;
+    p2p_ack_kernel<<<1, 64, 0, m->comm->stream>>>(n_nb, m->p2p->d_ack_ptr, seq, m->d_S, skip_if_done ? 1 : 0);
+    KMCF_HIP(hipGetLastError());
     return KMCF_OK;
 }
 
@@ -512,6 +542,10 @@ void kmcf_p2p_matrix_free(kmcf_matrix *m)
     if (m->p2p->d_put_stride) hipFree(m->p2p->d_put_stride);
     if (m->p2p->d_put_flag) hipFree(m->p2p->d_put_flag);
     if (m->p2p->d_ack_ptr) hipFree(m->p2p->d_ack_ptr);
+    if (m->p2p->d_put_row) hipFree(m->p2p->d_put_row);
+    if (m->p2p->d_putr_ptr) hipFree(m->p2p->d_putr_ptr);
+    if (m->p2p->d_putr_addr) hipFree(m->p2p->d_putr_addr);
+    if (m->p2p->d_putr_stride) hipFree(m->p2p->d_putr_stride);
     if (m->p2p->d_ctr) hipFree(m->p2p->d_ctr);
     delete m->p2p;
     m->p2p = nullptr;
@@ -527,10 +561,11 @@ int kmcf_p2p_halo_exchange(kmcf_matrix *m)
     if (n_nb <= 0) return KMCF_OK;
     KMCF_CHECK(h != nullptr, KMCF_ERR_STATE, "p2p halo: matrix was built before the transport was up");
     ++h->seq;
+    h->seq_put = h->seq;
     const int g = std::max(1, std::min((m->n_send + KMCF_BLOCK - 1) / KMCF_BLOCK, 64));
     p2p_put_kernel<<<g, KMCF_BLOCK, 0, c->comm_stream>>>(m->n_send, m->d_send_idx, m->d_p, h->d_put_ptr, h->d_put_stride, n_nb, h->d_put_flag,
                                                          reinterpret_cast<const u64 *>(w->win + h->ack_off), h->seq, w->timeout_ticks, w->d_err,
-                                                         w->h_err, h->d_ctr);
+                                                         w->h_err, h->d_ctr, nullptr, 0);
     const int g2 = std::max(1, std::min((m->n_halo + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4), 32));
     p2p_halo_wait_kernel<<<g2, KMCF_BLOCK, 0, c->comm_stream>>>(n_nb, reinterpret_cast<const u64 *>(w->win + h->flag_off), h->seq, w->timeout_ticks,
                                                                w->d_err, w->h_err, m->n_halo, reinterpret_cast<const double *>(w->win + h->land_off),

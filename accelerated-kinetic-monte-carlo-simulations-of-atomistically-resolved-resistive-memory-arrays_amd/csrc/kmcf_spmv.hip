@@ -31,7 +31,7 @@
 
 #include <climits>
 
-#include "kmcf_internal.hpp"
+#include "kmcf_p2p_dev.hpp"
 
 namespace {
 
@@ -597,6 +597,55 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_kernel(
     }
 }
 
+// The boundary-row pass of the "direct" peer-to-peer protocol (kmcf_p2p_dev.hpp): the same rows, lanes and sums as
+// spmv_vec_kernel<LPR, DOT, false, true>, but the block first waits (bounded) for the flags of this SpMV's halo and
+// then reads halo columns in place from buffer (seq & 1) of the landing zone in this rank's window -- no wait / copy
+// kernel, no second stream, no event between the interior rows and these.
+template <int LPR, bool DOT>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_halo_kernel(
+    int n_rows, const int *__restrict__ row_ptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ row_list, double *__restrict__ part,
+    const kmcf_scalars *__restrict__ S, int check_done, int n_loc, kmcf_p2p_dev pd, u64 seq)
+{
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    if ((int)threadIdx.x < pd.n_nb) wait_ge(&pd.flags[threadIdx.x], seq, pd.timeout, pd.d_err, pd.h_err, 2);
+    __syncthreads();
+    const bool ok = __hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    const double *land = pd.landing + (size_t)(seq & 1) * pd.n_halo;
+    constexpr int RPB = KMCF_BLOCK / LPR;
+    const int lane_in_row = threadIdx.x % LPR;
+    const int row_in_block = threadIdx.x / LPR;
+    const int G = (n_rows + RPB - 1) / RPB;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Gx = (G + 7) >> 3;
+    double dot = 0.0;
+    for (int g = bi; g < Gx && ok; g += nb8) {
+        const int grp = xcd * Gx + g;
+        const int row = grp * RPB + row_in_block;
+        const bool valid = (grp < G) && (row < n_rows);
+        const int r = valid ? row_list[row] : 0;
+        double s = 0.0;
+        if (valid) {
+            const int b = row_ptr[r], e = row_ptr[r + 1];
+            for (int j = b + lane_in_row; j < e; j += LPR) {
+                const int c = col[j];
+                const double xv = c >= n_loc ? load_system(land + (c - n_loc)) : x[c];
+                s += val[j] * xv;
+            }
+        }
+        s = wave_sum_width(s, LPR);
+        if (valid && lane_in_row == 0) {
+            y[r] = s;
+            if (DOT) dot += x[r] * s;
+        }
+    }
+    if (DOT) {
+        double t = block_sum_256(dot, lds4);
+        if (threadIdx.x == 0) part[blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------ long rows
 // Rows [n_short, n_loc): one block per chunk of KMCF_LONG_CHUNK entries; the last block to finish (atomic
 // counter) adds each row's chunk sums in chunk order and writes y -- deterministic, one launch.  Values always
@@ -719,6 +768,31 @@ void launch_vec_any(kmcf_matrix *m, bool with_dot, bool skip_if_done, bool bound
         case 32: launch_vec<32>(m, with_dot, skip_if_done, boundary_pass); break;
         case 64: launch_vec<64>(m, with_dot, skip_if_done, boundary_pass); break;
         default: launch_vec<16>(m, with_dot, skip_if_done, boundary_pass); break;
+    }
+}
+
+template <int LPR>
+void launch_vec_halo(kmcf_matrix *m, bool with_dot, bool skip_if_done, u64 seq)
+{
+    const kmcf_p2p_dev pd = kmcf_p2p_dev_of(m);
+    const int chk = skip_if_done ? 1 : 0;
+    if (with_dot)
+        spmv_vec_halo_kernel<LPR, true><<<m->spmv_grid_b, KMCF_BLOCK, 0, m->comm->stream>>>(
+            m->n_boundary_rows, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, m->d_boundary_rows, m->d_part_a + KMCF_MAX_PARTIALS,
+            m->d_S, chk, m->n_loc, pd, seq);
+    else
+        spmv_vec_halo_kernel<LPR, false><<<m->spmv_grid_b, KMCF_BLOCK, 0, m->comm->stream>>>(
+            m->n_boundary_rows, m->d_row_ptr, m->d_col, m->d_val, m->d_p, m->d_Ap, m->d_boundary_rows, nullptr, m->d_S, chk, m->n_loc, pd, seq);
+}
+
+void launch_vec_halo_any(kmcf_matrix *m, bool with_dot, bool skip_if_done, u64 seq)
+{
+    switch (m->spmv_lpr) {
+        case 4: launch_vec_halo<4>(m, with_dot, skip_if_done, seq); break;
+        case 8: launch_vec_halo<8>(m, with_dot, skip_if_done, seq); break;
+        case 32: launch_vec_halo<32>(m, with_dot, skip_if_done, seq); break;
+        case 64: launch_vec_halo<64>(m, with_dot, skip_if_done, seq); break;
+        default: launch_vec_halo<16>(m, with_dot, skip_if_done, seq); break;
     }
 }
 
@@ -1453,8 +1527,28 @@ int kmcf_halo_exchange_end(kmcf_matrix *m)
 // Distributed Ap = A p on the matrix workspace (d_p local part already filled):
 // halo exchange on the comm stream overlapped with the interior rows, then the
 // boundary rows (dspmv::gpu_packing_cam, dist_spmv_gpu_packing.cpp:106-228).
-int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags)
 {
+    if (kmcf_p2p_direct(m)) {
+        // "direct" peer-to-peer protocol: ONE stream, no pack / wait / copy kernels.  The halo of this SpMV (sequence
+        // seq) was put by the kernel that produced d_p (flags bit 0 unset and nothing put yet: a stand-alone put now);
+        // interior rows; boundary rows after a bounded wait for the flags, halo columns read in place; then the
+        // acknowledgement, by the caller's next kernel (flags bit 0) or a small kernel of its own.
+        u64 &seq = *kmcf_p2p_halo_seq(m, 0), &seq_put = *kmcf_p2p_halo_seq(m, 1);
+        ++seq;
+        if (seq_put < seq) {
+            KMCF_TRY(kmcf_p2p_direct_put(m, seq, skip_if_done));
+            seq_put = seq;
+        }
+        launch_interior(m, with_dot, skip_if_done);
+        KMCF_HIP(hipGetLastError());
+        if (m->n_halo > 0 && m->n_boundary_rows > 0) {
+            launch_vec_halo_any(m, with_dot, skip_if_done, seq);
+            KMCF_HIP(hipGetLastError());
+        }
+        if (!(flags & 1)) KMCF_TRY(kmcf_p2p_direct_ack(m, seq, skip_if_done));
+        return KMCF_OK;
+    }
     KMCF_TRY(kmcf_halo_exchange_begin(m));
     launch_interior(m, with_dot, skip_if_done);
     KMCF_HIP(hipGetLastError());

@@ -436,57 +436,37 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_init_kernel(int n, double *__r
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = t; part_bb[blockIdx.x] = u; }
 }
 
-template <bool PRECOND>
-__global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
-    int n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p, double *__restrict__ s,
-    double *__restrict__ z /* in: z, out: next z (SpMV input) */, const double *__restrict__ w,
-    const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta, part_ref pbb, kmcf_scalars *__restrict__ S,
-    int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz)
+// Three sums of partial arrays in one pass (the loads of all three in flight together, one barrier instead of six); each
+// sum is formed exactly as reduce_partials forms it (same per-thread sequence, same butterfly, same (w0 + w1) + (w2 + w3)).
+__device__ __forceinline__ void reduce_partials3(const part_ref &a, const part_ref &b, const part_ref &c, bool with_c,
+                                                 double (*lds)[4], double &ra, double &rb, double &rc)
 {
-    __shared__ double lds4[4];
-    if (S->done) return;
-    const double gamma = reduce_partials(pgamma, lds4);
-    const double delta = reduce_partials(pdelta, lds4);
-    double bb;
-    if (first) bb = reduce_partials(pbb, lds4);
-    else bb = S->bb;
-    const bool go = check_tol ? (gamma / bb > tol2) : true;
-    double beta = 0.0, alpha;
-    if (first) {
-        alpha = gamma / delta;
-    } else {
-        beta = gamma / S->rz[parity ^ 1];
-        alpha = gamma / (delta - beta * gamma / S->alpha[parity ^ 1]);
+    double va = 0.0, vb = 0.0, vc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int i = threadIdx.x; i < a.n[q]; i += KMCF_BLOCK) va += a.p[q][i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int i = threadIdx.x; i < b.n[q]; i += KMCF_BLOCK) vb += b.p[q][i];
+    if (with_c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int i = threadIdx.x; i < c.n[q]; i += KMCF_BLOCK) vc += c.p[q][i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        S->rz_last = gamma;
-        if (first) S->bb = bb;
-        if (go) { S->rz[parity] = gamma; S->alpha[parity] = alpha; S->pAp = delta; S->iters += 1; }
-        else S->done = 1;
-    }
-    if (!go) return;
-    const double na = -alpha;
-    double rz = 0.0;
-    for (int i = blockIdx.x * KMCF_BLOCK + threadIdx.x; i < n; i += gridDim.x * KMCF_BLOCK) {
-        const double zi = z[i], wi = w[i];
-        const double pi = first ? zi : zi + beta * p[i];
-        const double si = first ? wi : wi + beta * s[i];
-        p[i] = pi;
-        s[i] = si;
-        x[i] = x[i] + alpha * pi;
-        const double ri = r[i] + na * si;
-        r[i] = ri;
-        const double zn = PRECOND ? ri * dinv[i] : ri;
-        z[i] = zn;
-        rz += ri * zn;
-    }
-    double t = block_sum(rz, lds4);
-    if (threadIdx.x == 0) part_rz[blockIdx.x] = t;
+    va = wave_sum64(va); vb = wave_sum64(vb); vc = wave_sum64(vc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { lds[0][w] = va; lds[1][w] = vb; lds[2][w] = vc; }
+    __syncthreads();
+    ra = (lds[0][0] + lds[0][1]) + (lds[0][2] + lds[0][3]);
+    rb = (lds[1][0] + lds[1][1]) + (lds[1][2] + lds[1][3]);
+    rc = (lds[2][0] + lds[2][1]) + (lds[2][2] + lds[2][3]);
+    __syncthreads();                     // (lds is written again by the caller's block_sum, with no barrier of the caller's in between)
 }
 
-
-// The same update with the group's exchanges folded in ("direct" peer-to-peer protocol, kmcf_p2p_dev.hpp): ONE kernel
-// per iteration besides the SpMV's two.
+// The update of the single-reduction loop, for one rank or a host-synchronous group (P2P = false: gamma, delta, b.b are
+// the sums of the partial arrays, i.e. of the ONE all-reduced value each when a group's transport reduced them), or with
+// the group's exchanges folded in (P2P = true, the "direct" peer-to-peer protocol, kmcf_p2p_dev.hpp): ONE kernel per
+// iteration besides the SpMV's two.
 //   * all-reduce: every block forms this rank's sums of gamma, delta (and b.b) from the partial arrays; block 0 stores
 //     them into slot [parity][rank] of every peer's window and raises its flag there; every block waits (bounded)
 //     for the P flags of its OWN window and adds the P slots in rank order -- the same numbers in the same order on
@@ -495,60 +475,82 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
 //   * put: the thread that computes the new z of a row a neighbour needs stores it into buffer (seq_put & 1) of that
 //     neighbour's landing zone (after the acknowledgements of seq_put - 2 are in: every block checks); the last block
 //     to finish raises the neighbours' flags -- the halo of the NEXT SpMV is on its way while this kernel still runs.
-// Arithmetic and summation order are cg1_update_kernel's (the loopback transport runs that one: iterates bit-identical).
-template <bool PRECOND>
-__global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_p2p_kernel(
+// Both variants: same arithmetic, same summation order (two rows per lane and step, like cg_xr_kernel), so a group's
+// iterates do not depend on its transport.  A block lives for one or two steps: scalars, partial sums and the block's
+// first elements are all requested before the first wait (a kernel of this size is a chain of memory round trips;
+// measured on a rank's eighth of the 40 nm matrix: 9.8 us with the chain done -> reduce -> reduce -> reduce -> loop).
+template <bool PRECOND, bool P2P>
+__global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
     int n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p, double *__restrict__ s,
-    double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta,
-    part_ref pbb, kmcf_scalars *__restrict__ S, int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz,
-    kmcf_p2p_dev pd, u64 seq_red, u64 seq_ack, u64 seq_put)
+    double *__restrict__ z /* in: z, out: next z (SpMV input) */, const double *__restrict__ w,
+    const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta, part_ref pbb, kmcf_scalars *__restrict__ S,
+    int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz, kmcf_p2p_dev pd, u64 seq_red,
+    u64 seq_ack, u64 seq_put)
 {
-    __shared__ double lds4[4];
+    __shared__ double lds[3][4];
     __shared__ double red[4];
     __shared__ int s_last;
-    if (S->done) return;
-    const int t = threadIdx.x, rpar = (int)(seq_red & 1);
-    const double g_loc = reduce_partials(pgamma, lds4);
-    const double d_loc = reduce_partials(pdelta, lds4);
-    const double b_loc = first ? reduce_partials(pbb, lds4) : 0.0;
-    if (blockIdx.x == 0) {
-        if (t < pd.P) {
-            double *slot = reinterpret_cast<double *>(pd.peer[t] + P2P_OFF_RED_SLOT) + ((size_t)rpar * P2P_MAXR + pd.rank) * 4;
-            store_system(&slot[0], g_loc);
-            store_system(&slot[1], d_loc);
-            store_system(&slot[2], b_loc);
-            store_release_system(reinterpret_cast<u64 *>(pd.peer[t] + P2P_OFF_RED_FLAG) + (size_t)rpar * P2P_MAXR + pd.rank, seq_red);
-        } else if (t >= 64 && t < 64 + pd.n_nb) {
-            store_release_system(pd.ack_ptr[t - 64], seq_ack);
+    const int t = threadIdx.x;
+    const int n2 = n >> 1;
+    const int i0 = blockIdx.x * KMCF_BLOCK + t;
+    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *p2 = reinterpret_cast<double2 *>(p),
+            *s2 = reinterpret_cast<double2 *>(s), *z2 = reinterpret_cast<double2 *>(z);
+    const double2 *w2 = reinterpret_cast<const double2 *>(w), *d2 = reinterpret_cast<const double2 *>(dinv);
+    // ---- everything this block needs, requested at once
+    const int done = S->done;
+    const double bb_saved = S->bb, rz_prev = S->rz[parity ^ 1], alpha_prev = S->alpha[parity ^ 1];
+    const double2 zero = make_double2(0.0, 0.0);
+    double2 zv0 = zero, wv0 = zero, pv0 = zero, sv0 = zero, xv0 = zero, rv0 = zero, dv0 = make_double2(1.0, 1.0);
+    int2 pr0 = make_int2(-1, -1);
+    if (i0 < n2) {
+        zv0 = z2[i0]; wv0 = w2[i0]; xv0 = x2[i0]; rv0 = r2[i0];
+        if (!first) { pv0 = p2[i0]; sv0 = s2[i0]; }
+        if (PRECOND) dv0 = d2[i0];
+        if (P2P) pr0 = reinterpret_cast<const int2 *>(pd.put_row)[i0];
+    }
+    double gamma, delta, bsum;
+    reduce_partials3(pgamma, pdelta, pbb, first != 0, lds, gamma, delta, bsum);
+    if (done) return;
+    if (P2P) {
+        const int rpar = (int)(seq_red & 1);
+        if (blockIdx.x == 0) {
+            if (t < pd.P) {
+                double *slot = reinterpret_cast<double *>(pd.peer[t] + P2P_OFF_RED_SLOT) + ((size_t)rpar * P2P_MAXR + pd.rank) * P2P_FS;
+                store_system(&slot[0], gamma);
+                store_system(&slot[1], delta);
+                store_system(&slot[2], first ? bsum : 0.0);
+                store_release_system(reinterpret_cast<u64 *>(pd.peer[t] + P2P_OFF_RED_FLAG) + ((size_t)rpar * P2P_MAXR + pd.rank) * P2P_FS, seq_red);
+            } else if (t >= 64 && t < 64 + pd.n_nb) {
+                store_release_system(pd.ack_ptr[t - 64], seq_ack);
+            }
         }
+        if (t < pd.P)
+            wait_ge(reinterpret_cast<const u64 *>(pd.peer[pd.rank] + P2P_OFF_RED_FLAG) + ((size_t)rpar * P2P_MAXR + t) * P2P_FS, seq_red, pd.timeout,
+                    pd.d_err, pd.h_err, 1);
+        else if (t >= 64 && t < 64 + pd.n_nb && seq_put > 2)
+            wait_ge(&pd.acks[(t - 64) * P2P_FS], seq_put - 2, pd.timeout, pd.d_err, pd.h_err, 5);
+        __syncthreads();
+        if (__hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (t < 3) {
+            const double *slots = reinterpret_cast<const double *>(pd.peer[pd.rank] + P2P_OFF_RED_SLOT) + (size_t)rpar * P2P_MAXR * P2P_FS;
+            double v = 0.0;
+            for (int q = 0; q < pd.P; ++q) v += load_system(&slots[(size_t)q * P2P_FS + t]);      // rank order on every rank
+            red[t] = v;
+        }
+        __syncthreads();
+        gamma = red[0]; delta = red[1]; bsum = red[2];
     }
-    if (t < pd.P)
-        wait_ge(reinterpret_cast<const u64 *>(pd.peer[pd.rank] + P2P_OFF_RED_FLAG) + (size_t)rpar * P2P_MAXR + t, seq_red, pd.timeout, pd.d_err,
-                pd.h_err, 1);
-    else if (t >= 64 && t < 64 + pd.n_nb && seq_put > 2)
-        wait_ge(&pd.acks[t - 64], seq_put - 2, pd.timeout, pd.d_err, pd.h_err, 5);
-    __syncthreads();
-    if (__hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    if (t < 3) {
-        const double *slots = reinterpret_cast<const double *>(pd.peer[pd.rank] + P2P_OFF_RED_SLOT) + (size_t)rpar * P2P_MAXR * 4;
-        double v = 0.0;
-        for (int q = 0; q < pd.P; ++q) v += load_system(&slots[(size_t)q * 4 + t]);      // rank order on every rank
-        red[t] = v;
-    }
-    __syncthreads();
-    const double gamma = red[0], delta = red[1];
-    const double bb = first ? red[2] : S->bb;
+    const double bb = first ? bsum : bb_saved;
     const bool go = check_tol ? (gamma / bb > tol2) : true;
     double beta = 0.0, alpha;
     if (first) {
         alpha = gamma / delta;
     } else {
-        beta = gamma / S->rz[parity ^ 1];
-        alpha = gamma / (delta - beta * gamma / S->alpha[parity ^ 1]);
+        beta = gamma / rz_prev;
+        alpha = gamma / (delta - beta * gamma / alpha_prev);
     }
     if (blockIdx.x == 0 && t == 0) {
         S->rz_last = gamma;
-        S->red[0] = gamma; S->red[1] = delta; S->red[2] = first ? red[2] : 0.0;
         if (first) S->bb = bb;
         if (go) { S->rz[parity] = gamma; S->alpha[parity] = alpha; S->pAp = delta; S->iters += 1; }
         else S->done = 1;
@@ -557,35 +559,54 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_p2p_kernel(
     const double na = -alpha;
     const long long ppar = (long long)(seq_put & 1);
     double rz = 0.0;
-    for (int i = blockIdx.x * KMCF_BLOCK + t; i < n; i += gridDim.x * KMCF_BLOCK) {
-        const double zi = z[i], wi = w[i];
-        const double pi = first ? zi : zi + beta * p[i];
-        const double si = first ? wi : wi + beta * s[i];
-        p[i] = pi;
-        s[i] = si;
-        x[i] = x[i] + alpha * pi;
-        const double ri = r[i] + na * si;
-        r[i] = ri;
-        const double zn = PRECOND ? ri * dinv[i] : ri;
-        z[i] = zn;
+    // one element of one row: p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = r .* dinv ; r.z
+    auto upd = [&](double zi, double wi, double &pi, double &si, double &xi, double &ri, double di, double &zn, int prow) {
+        pi = first ? zi : zi + beta * pi;
+        si = first ? wi : wi + beta * si;
+        xi = xi + alpha * pi;
+        ri = ri + na * si;
+        zn = PRECOND ? ri * di : ri;
         rz += ri * zn;
-        const int b = pd.put_row[i];
-        if (b >= 0)
-            for (int e = pd.putr_ptr[b]; e < pd.putr_ptr[b + 1]; ++e) store_system(pd.putr_addr[e] + ppar * pd.putr_stride[e], zn);
+        if (P2P && prow >= 0)
+            for (int e = pd.putr_ptr[prow]; e < pd.putr_ptr[prow + 1]; ++e) store_system(pd.putr_addr[e] + ppar * pd.putr_stride[e], zn);
+    };
+    if (i0 < n2) {                                              // (the prefetched step)
+        double2 zn;
+        upd(zv0.x, wv0.x, pv0.x, sv0.x, xv0.x, rv0.x, dv0.x, zn.x, pr0.x);
+        upd(zv0.y, wv0.y, pv0.y, sv0.y, xv0.y, rv0.y, dv0.y, zn.y, pr0.y);
+        p2[i0] = pv0; s2[i0] = sv0; x2[i0] = xv0; r2[i0] = rv0; z2[i0] = zn;
     }
-    const double tsum = block_sum(rz, lds4);
+    for (int i = i0 + gridDim.x * KMCF_BLOCK; i < n2; i += gridDim.x * KMCF_BLOCK) {
+        const double2 zv = z2[i], wv = w2[i];
+        double2 pv = first ? zero : p2[i], sv = first ? zero : s2[i], xv = x2[i], rv = r2[i];
+        const double2 dv = PRECOND ? d2[i] : make_double2(1.0, 1.0);
+        const int2 pr = P2P ? reinterpret_cast<const int2 *>(pd.put_row)[i] : make_int2(-1, -1);
+        double2 zn;
+        upd(zv.x, wv.x, pv.x, sv.x, xv.x, rv.x, dv.x, zn.x, pr.x);
+        upd(zv.y, wv.y, pv.y, sv.y, xv.y, rv.y, dv.y, zn.y, pr.y);
+        p2[i] = pv; s2[i] = sv; x2[i] = xv; r2[i] = rv; z2[i] = zn;
+    }
+    if ((n & 1) && blockIdx.x == 0 && t == 0) {
+        const int i = n - 1;
+        double pi = first ? 0.0 : p[i], si = first ? 0.0 : s[i], xi = x[i], ri = r[i], zn;
+        upd(z[i], w[i], pi, si, xi, ri, PRECOND ? dinv[i] : 1.0, zn, P2P ? pd.put_row[i] : -1);
+        p[i] = pi; s[i] = si; x[i] = xi; r[i] = ri; z[i] = zn;
+    }
+    const double tsum = block_sum(rz, &lds[0][0]);
     if (t == 0) part_rz[blockIdx.x] = tsum;
-    // the last block to finish raises the neighbours' flags
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(pd.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (P2P) {
+        // the last block to finish raises the neighbours' flags
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = __hip_atomic_fetch_add(pd.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (t < pd.n_nb) store_release_system(pd.put_flag[t], seq_put);
+        if (t == 0) __hip_atomic_store(pd.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (!s_last) return;
-    if (t < pd.n_nb) store_release_system(pd.put_flag[t], seq_put);
-    if (t == 0) __hip_atomic_store(pd.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 1-block finalize for the multi-rank case: red[0] = gamma, red[1] = delta, red[2] = bb partial (first only)
@@ -649,9 +670,9 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             KMCF_TRY(kmcf_spmv_device(m, true, true, fused ? 1 : 0));  // w = A z, delta partials
             if (fused) {
                 const u64 sr = kmcf_p2p_next_red_seq(c), sh = *kmcf_p2p_halo_seq(m, 0);
-                cg1_update_p2p_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
-                                                                          pg_loc, pd_loc, pb_loc, S, parity, first, tol2, check_tol,
-                                                                          m->d_part_b, kmcf_p2p_dev_of(m), sr, sh, sh + 1);
+                cg1_update_kernel<PRECOND, true><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
+                                                                            pg_loc, pd_loc, pb_loc, S, parity, first, tol2, check_tol,
+                                                                            m->d_part_b, kmcf_p2p_dev_of(m), sr, sh, sh + 1);
                 KMCF_HIP(hipGetLastError());
                 *kmcf_p2p_halo_seq(m, 1) = sh + 1;                      // the halo of the next SpMV is put
                 continue;
@@ -668,9 +689,9 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
                 KMCF_HIP(hipGetLastError());
                 KMCF_TRY(kmcf_comm_allreduce_sum(c, &S->red[0], 3));
             }
-            cg1_update_kernel<PRECOND><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap,
-                                                                  m->d_dinv, pg, pd, pb, S, parity, first, tol2,
-                                                                  check_tol, m->d_part_b);
+            cg1_update_kernel<PRECOND, false><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap,
+                                                                         m->d_dinv, pg, pd, pb, S, parity, first, tol2,
+                                                                         check_tol, m->d_part_b, kmcf_p2p_dev{}, 0, 0, 0);
             KMCF_HIP(hipGetLastError());
         }
         launched += chunk;
@@ -714,7 +735,19 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
 }  // namespace
 
 // Solve on the matrix workspace: m->d_r holds b, m->d_x the start guess, m->d_dinv 1/diag.
+static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags);
+
 static int pcg_workspace_flags(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
+{
+    kmcf_comm *c = m->comm;
+    KMCF_TRY(kmcf_group_rendezvous(c));                   // (in-process test groups: see kmcf_internal.hpp)
+    c->in_solve = true;
+    const int rc = pcg_workspace_run(m, precond, tol, max_it, fixed_iters, stats, flags);
+    c->in_solve = false;
+    return rc;
+}
+
+static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
 {
     // classic = the reference's recurrence and operation order (default for one rank);
     // cg1r = single-reduction variant (default for multi-rank groups)

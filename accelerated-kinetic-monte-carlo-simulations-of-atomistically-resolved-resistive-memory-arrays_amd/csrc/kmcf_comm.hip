@@ -411,6 +411,13 @@ int loopback_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
 
 }  // namespace
 
+int kmcf_group_rendezvous(kmcf_comm *c)
+{
+    if (!c->group || !c->p2p_active || c->nranks <= 1 || c->in_solve) return KMCF_OK;
+    group_barrier(c->group);
+    return KMCF_OK;
+}
+
 // All P ranks of an in-process loopback group at once (out: array of nranks communicators); each is
 // then driven by its own host thread.
 extern "C" int kmcf_comm_create_loopback(kmcf_comm **out, int device, int nranks)
@@ -471,7 +478,10 @@ extern "C" const char *kmcf_comm_transport(const kmcf_comm *c)
 // Sum `count` doubles in place over all ranks, on the compute stream, device resident.
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count)
 {
-    if (c->p2p_active && c->nranks > 1) return kmcf_p2p_allreduce(c, d_buf, count);
+    if (c->p2p_active && c->nranks > 1) {
+        KMCF_TRY(kmcf_group_rendezvous(c));
+        return kmcf_p2p_allreduce(c, d_buf, count);
+    }
     if (c->group) return c->group->nranks > 1 ? loopback_allreduce(c, d_buf, count) : KMCF_OK;
     if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
     KMCF_CHECK(c->nccl_red, KMCF_ERR_COMM, "communicator not connected (call kmcf_comm_connect)");
@@ -511,8 +521,10 @@ static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int 
     // gathers that fit the window's staging area go peer to peer; the rare big ones (the neighbour lists of the
     // replicated event step, once per run) take the transport underneath
     if (c->p2p_active && c->nranks > 1 &&
-        kmcf_p2p_fits(c, ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(T)))
+        kmcf_p2p_fits(c, ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(T))) {
+        KMCF_TRY(kmcf_group_rendezvous(c));
         return kmcf_p2p_allgatherv(c, d_buf, counts, displs, sizeof(T));
+    }
     if (c->p2p_active && c->nranks > 1 && !c->group && !c->nccl_red) {
         kmcf_set_error("all-gather of %zu bytes exceeds the p2p staging area and no other transport is connected (KMCF_P2P_WINDOW_MB)",
                        ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(T));

@@ -87,6 +87,7 @@ struct kmcf_comm {
     kmcf_group *group = nullptr;        // loopback transport (nullptr: RCCL)
     kmcf_p2p *p2p = nullptr;            // mapped peer windows; used for the exchanges while p2p_active
     bool p2p_active = false;
+    bool in_solve = false;              // inside a CG loop: its per-iteration exchanges never meet on the host (kmcf_group_rendezvous)
     int device = 0;
     int nranks = 1;
     int rank = 0;
@@ -333,6 +334,12 @@ int kmcf_halo_exchange_end(kmcf_matrix *m);     // compute stream waits for the 
 // caller's stream are complete before any library kernel reads them).
 int kmcf_enter(kmcf_comm *c);
 int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count);
+// In-process groups on the peer-to-peer transport only (ranks = host threads sharing ONE GPU, a test device): the
+// members meet on the host before an exchange whose kernels wait for each other on the device.  A member that is
+// still inside a call that waits for the whole device (hipFree does) while another member's kernel already waits,
+// on that device, for this member's next kernel, would otherwise block until the bounded wait expires (seen as
+// intermittent time-outs of the set-up all-gathers).  Between processes -- one device each -- no such coupling exists.
+int kmcf_group_rendezvous(kmcf_comm *c);
 int kmcf_comm_send_recv_halo(kmcf_matrix *m);
 int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);
 int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs);

@@ -329,8 +329,8 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
             tab[(size_t)W * rank + q] = (int)m->rows_per_neighbour[k].size();
             tab[(size_t)W * rank + P + q] = (int)m->cols_per_neighbour[k].size();
             tab[(size_t)W * rank + 2 * P + q] = land8 + m->halo_offset[k];       // neighbour q's values land at its halo slots
-            tab[(size_t)W * rank + 3 * P + q] = flag8 + (k - 1);
-            tab[(size_t)W * rank + 4 * P + q] = ack8 + (k - 1);                  // q acknowledges MY puts here
+            tab[(size_t)W * rank + 3 * P + q] = flag8 + (k - 1) * 16;               // (one 128-byte line per flag: P2P_FS)
+            tab[(size_t)W * rank + 4 * P + q] = ack8 + (k - 1) * 16;                // q acknowledges MY puts here
             tab[(size_t)W * rank + 5 * P + q] = std::max(m->n_halo, 1);
         }
         // (kept until the matrix is destroyed: hipFree waits for EVERY stream of the process, and in an in-process group

@@ -40,19 +40,19 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_kernel(char *const *
 {
     const int t = threadIdx.x, parity = (int)(seq & 1);
     if (t < P) {
-        double *slot = reinterpret_cast<double *>(peer[t] + P2P_OFF_RED_SLOT) + ((size_t)parity * P2P_MAXR + rank) * 4;
+        double *slot = reinterpret_cast<double *>(peer[t] + P2P_OFF_RED_SLOT) + ((size_t)parity * P2P_MAXR + rank) * P2P_FS;
         for (int i = 0; i < count; ++i)
             __hip_atomic_store(reinterpret_cast<u64 *>(&slot[i]), (u64)__double_as_longlong(buf[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        store_release_system(reinterpret_cast<u64 *>(peer[t] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + rank, seq);
+        store_release_system(reinterpret_cast<u64 *>(peer[t] + P2P_OFF_RED_FLAG) + ((size_t)parity * P2P_MAXR + rank) * P2P_FS, seq);
     }
     __syncthreads();
-    if (t < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + t, seq, timeout, d_err, h_err, 1);
+    if (t < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_RED_FLAG) + ((size_t)parity * P2P_MAXR + t) * P2P_FS, seq, timeout, d_err, h_err, 1);
     __syncthreads();
     if (t < count && __hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        const double *slots = reinterpret_cast<const double *>(peer[rank] + P2P_OFF_RED_SLOT) + (size_t)parity * P2P_MAXR * 4;
+        const double *slots = reinterpret_cast<const double *>(peer[rank] + P2P_OFF_RED_SLOT) + (size_t)parity * P2P_MAXR * P2P_FS;
         double s = 0.0;
         for (int q = 0; q < P; ++q)            // rank order on every rank: identical sums everywhere
-            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&slots[(size_t)q * 4 + t]), __ATOMIC_RELAXED,
+            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&slots[(size_t)q * P2P_FS + t]), __ATOMIC_RELAXED,
                                                                    __HIP_MEMORY_SCOPE_SYSTEM));
         buf[t] = s;
     }
@@ -81,19 +81,19 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_parts_kernel(char *c
         __syncthreads();
     }
     if (t < P) {
-        double *slot = reinterpret_cast<double *>(peer[t] + P2P_OFF_RED_SLOT) + ((size_t)parity * P2P_MAXR + rank) * 4;
+        double *slot = reinterpret_cast<double *>(peer[t] + P2P_OFF_RED_SLOT) + ((size_t)parity * P2P_MAXR + rank) * P2P_FS;
         for (int i = 0; i < count; ++i)
             __hip_atomic_store(reinterpret_cast<u64 *>(&slot[i]), (u64)__double_as_longlong(mine[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        store_release_system(reinterpret_cast<u64 *>(peer[t] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + rank, seq);
+        store_release_system(reinterpret_cast<u64 *>(peer[t] + P2P_OFF_RED_FLAG) + ((size_t)parity * P2P_MAXR + rank) * P2P_FS, seq);
     }
     __syncthreads();
-    if (t < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_RED_FLAG) + (size_t)parity * P2P_MAXR + t, seq, timeout, d_err, h_err, 1);
+    if (t < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_RED_FLAG) + ((size_t)parity * P2P_MAXR + t) * P2P_FS, seq, timeout, d_err, h_err, 1);
     __syncthreads();
     if (t < count && __hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        const double *slots = reinterpret_cast<const double *>(peer[rank] + P2P_OFF_RED_SLOT) + (size_t)parity * P2P_MAXR * 4;
+        const double *slots = reinterpret_cast<const double *>(peer[rank] + P2P_OFF_RED_SLOT) + (size_t)parity * P2P_MAXR * P2P_FS;
         double s = 0.0;
         for (int q = 0; q < P; ++q)
-            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&slots[(size_t)q * 4 + t]), __ATOMIC_RELAXED,
+            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(&slots[(size_t)q * P2P_FS + t]), __ATOMIC_RELAXED,
                                                                    __HIP_MEMORY_SCOPE_SYSTEM));
         S->red[t] = s;
     }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_put_kernel(int n_send, const i
 {
     __shared__ int s_last;
     if (check_done && S->done) return;
-    if ((int)threadIdx.x < n_nb && seq > 2) wait_ge(&acks[threadIdx.x], seq - 2, timeout, d_err, h_err, 5);
+    if ((int)threadIdx.x < n_nb && seq > 2) wait_ge(&acks[threadIdx.x * P2P_FS], seq - 2, timeout, d_err, h_err, 5);
     __syncthreads();
     const long long par = (long long)(seq & 1);
     if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)      // (never overwrite an unconsumed buffer)
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_halo_wait_kernel(int n_nb, con
                                                                    unsigned int *__restrict__ ctr)
 {
     __shared__ int s_last;
-    if ((int)threadIdx.x < n_nb) wait_ge(&flags[threadIdx.x], seq, timeout, d_err, h_err, 2);
+    if ((int)threadIdx.x < n_nb) wait_ge(&flags[threadIdx.x * P2P_FS], seq, timeout, d_err, h_err, 2);
     __syncthreads();
     if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const double *src = landing + (size_t)(seq & 1) * n_halo;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_gather_stage_kernel(char *cons
 {
     __shared__ int s_last;
     if ((int)threadIdx.x < P && seq > 2)
-        wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_G_ACK) + threadIdx.x, seq - 2, timeout, d_err, h_err, 4);
+        wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_G_ACK) + threadIdx.x * P2P_FS, seq - 2, timeout, d_err, h_err, 4);
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
         __hip_atomic_store(&stage[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -178,7 +178,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_gather_stage_kernel(char *cons
     }
     __syncthreads();
     if (!s_last) return;
-    if ((int)threadIdx.x < P) store_release_system(reinterpret_cast<u64 *>(peer[threadIdx.x] + P2P_OFF_G_FLAG) + rank, seq);
+    if ((int)threadIdx.x < P) store_release_system(reinterpret_cast<u64 *>(peer[threadIdx.x] + P2P_OFF_G_FLAG) + rank * P2P_FS, seq);
+#ifdef KMCF_P2P_DEBUG
+    if ((int)threadIdx.x < P) printf("gather stage: rank %d wrote seq %llu to %p (peer %d)\n", rank, seq, (void *)(reinterpret_cast<u64 *>(peer[threadIdx.x] + P2P_OFF_G_FLAG) + rank * P2P_FS), (int)threadIdx.x);
+#endif
     if (threadIdx.x == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_gather_pull_kernel(char *const
                                                                      unsigned int *__restrict__ ctr)
 {
     __shared__ int s_last;
-    if ((int)threadIdx.x < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_G_FLAG) + threadIdx.x, seq, timeout, d_err, h_err, 3);
+    if ((int)threadIdx.x < P) wait_ge(reinterpret_cast<const u64 *>(peer[rank] + P2P_OFF_G_FLAG) + threadIdx.x * P2P_FS, seq, timeout, d_err, h_err, 3);
     __syncthreads();
     if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         for (int q = 0; q < P; ++q) {
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_gather_pull_kernel(char *const
     }
     __syncthreads();
     if (!s_last) return;
-    if ((int)threadIdx.x < P) store_release_system(reinterpret_cast<u64 *>(peer[threadIdx.x] + P2P_OFF_G_ACK) + rank, seq);
+    if ((int)threadIdx.x < P) store_release_system(reinterpret_cast<u64 *>(peer[threadIdx.x] + P2P_OFF_G_ACK) + rank * P2P_FS, seq);
     if (threadIdx.x == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -408,8 +411,8 @@ int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *a
     const int n_nb = m->number_of_neighbours - 1;
     h->land_off = align_up(w->bump, 256);
     h->flag_off = align_up(h->land_off + 2 * (size_t)std::max(m->n_halo, 1) * sizeof(double), 256);     // two buffers (sequence parity)
-    h->ack_off = align_up(h->flag_off + (size_t)std::max(n_nb, 1) * sizeof(u64), 256);
-    const size_t end = h->ack_off + (size_t)std::max(n_nb, 1) * sizeof(u64);
+    h->ack_off = align_up(h->flag_off + (size_t)std::max(n_nb, 1) * P2P_FS * sizeof(u64), 256);      // (one line per flag)
+    const size_t end = h->ack_off + (size_t)std::max(n_nb, 1) * P2P_FS * sizeof(u64);
     KMCF_CHECK(end <= w->win_bytes, KMCF_ERR_NOMEM, "p2p window exhausted (%zu of %zu bytes; KMCF_P2P_WINDOW_MB)", end, w->win_bytes);
     w->bump = end;
     KMCF_HIP(hipMemset(w->win + h->flag_off, 0, end - h->flag_off));

@@ -5,11 +5,17 @@
 #include "kmcf_internal.hpp"
 
 constexpr int P2P_MAXR = 64;
-constexpr size_t P2P_OFF_RED_SLOT = 0;       // double [2][MAXR][4]
-constexpr size_t P2P_OFF_RED_FLAG = 4096;    // u64    [2][MAXR]
-constexpr size_t P2P_OFF_G_FLAG = 5120;      // u64    [MAXR]   published gather sequence of rank q (written by q)
-constexpr size_t P2P_OFF_G_ACK = 5632;       // u64    [MAXR]   gather sequence rank q has consumed from me
-constexpr size_t P2P_OFF_BUMP = 8192;
+// Every flag and every all-reduce slot is a 128-byte line of its own (P2P_FS 8-byte words): no line has two writers,
+// and the window's owner never writes a line it polls.  (With several flags of different writers in one line, the
+// owner's own store could leave the line in its L2 -- each XCD has its own -- and its polls of the NEIGHBOURING words,
+// which a peer had meanwhile written to memory, kept hitting that copy: seen as intermittent time-outs of in-process
+// groups.)
+constexpr int P2P_FS = 16;
+constexpr size_t P2P_OFF_RED_SLOT = 0;                                       // double [2][MAXR][P2P_FS]  (4 used)
+constexpr size_t P2P_OFF_RED_FLAG = P2P_OFF_RED_SLOT + 2 * P2P_MAXR * 128;   // u64    [2][MAXR][P2P_FS]
+constexpr size_t P2P_OFF_G_FLAG = P2P_OFF_RED_FLAG + 2 * P2P_MAXR * 128;     // u64    [MAXR][P2P_FS]   published gather sequence of rank q (written by q)
+constexpr size_t P2P_OFF_G_ACK = P2P_OFF_G_FLAG + P2P_MAXR * 128;            // u64    [MAXR][P2P_FS]   gather sequence rank q has consumed from me
+constexpr size_t P2P_OFF_BUMP = P2P_OFF_G_ACK + P2P_MAXR * 128;
 
 typedef unsigned long long u64;
 
@@ -60,7 +66,7 @@ struct kmcf_p2p_dev {
     long long timeout;
     int *d_err, *h_err;
     int n_nb;                                // neighbours (k >= 1)
-    const u64 *flags;                        // my window: flag of neighbour k's puts
+    const u64 *flags;                        // my window: flag of neighbour k's puts at [k * P2P_FS] (acks alike)
     const u64 *acks;                         // my window: neighbour k's acknowledgement of MY puts
     u64 *const *ack_ptr;                     // neighbour k's window: my acknowledgement of ITS puts
     u64 *const *put_flag;                    // neighbour k's window: the flag of my puts
@@ -92,9 +98,17 @@ __device__ __forceinline__ void store_release_system(u64 *p, u64 v)
 __device__ __forceinline__ bool wait_ge(const u64 *p, u64 v, long long timeout, int *d_err, int *h_err, int code)
 {
     const long long t0 = wall_clock64();
+#ifdef KMCF_P2P_POLL_RMW
+    while (__hip_atomic_fetch_add(const_cast<u64 *>(p), 0ull, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+#else
     while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+#endif
         if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // already failed
         if (wall_clock64() - t0 > timeout) {
+#ifdef KMCF_P2P_DEBUG
+            printf("p2p wait timeout: code %d want %llu have %llu at %p (block %d thread %d)\n", code, v,
+                   (unsigned long long)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM), (const void *)p, (int)blockIdx.x, (int)threadIdx.x);
+#endif
             __hip_atomic_store(d_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(h_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;

@@ -609,7 +609,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_halo_kernel(
 {
     __shared__ double lds4[4];
     if (check_done && S->done) return;
-    if ((int)threadIdx.x < pd.n_nb) wait_ge(&pd.flags[threadIdx.x], seq, pd.timeout, pd.d_err, pd.h_err, 2);
+    if ((int)threadIdx.x < pd.n_nb) wait_ge(&pd.flags[threadIdx.x * P2P_FS], seq, pd.timeout, pd.d_err, pd.h_err, 2);
     __syncthreads();
     const bool ok = __hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     const double *land = pd.landing + (size_t)(seq & 1) * pd.n_halo;
@@ -1642,6 +1642,7 @@ extern "C" int kmcf_spmv(kmcf_matrix *m, const double *d_p, double *d_Ap)
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_TRY(kmcf_enter(c));
+    KMCF_TRY(kmcf_group_rendezvous(c));
     KMCF_TRY(kmcf_vec_in(m, m->d_p, d_p));
     KMCF_TRY(kmcf_spmv_device(m, false, false));
     KMCF_TRY(kmcf_vec_out(m, d_Ap, m->d_Ap));
@@ -1655,6 +1656,9 @@ extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_spmv_bench: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_TRY(kmcf_enter(c));
+    KMCF_TRY(kmcf_group_rendezvous(c));
+    c->in_solve = true;
+    struct leave_t { kmcf_comm *c; ~leave_t() { c->in_solve = false; } } leave{c};
     KMCF_HIP(hipEventRecord(c->ev_t0, c->stream));
     for (int i = 0; i < reps; ++i) KMCF_TRY(kmcf_spmv_device(m, with_dot != 0, false));
     KMCF_HIP(hipEventRecord(c->ev_t1, c->stream));
@@ -1672,6 +1676,9 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_comm_bench: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_TRY(kmcf_enter(c));
+    KMCF_TRY(kmcf_group_rendezvous(c));
+    c->in_solve = true;
+    struct leave_t { kmcf_comm *c; ~leave_t() { c->in_solve = false; } } leave{c};
     KMCF_HIP(hipMemsetAsync(&m->d_S->red[0], 0, 3 * sizeof(double), c->stream));
     KMCF_HIP(hipEventRecord(c->ev_t0, c->stream));
     for (int i = 0; i < reps; ++i) {

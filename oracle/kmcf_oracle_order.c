@@ -295,7 +295,6 @@ int orc_pcg1_device_order(int n, const int *rp, const int *col, const double *va
         a_par[parity] = alpha;
         iters += 1;
         const double na = -alpha;
-        for (int i = 0; i < T; ++i) acc1[i] = 0.0;
         for (int i = 0; i < n; ++i) {
             const double zi = z[i], wi = w[i];
             const double pi = first ? zi : zi + beta * p[i];
@@ -305,11 +304,9 @@ int orc_pcg1_device_order(int n, const int *rp, const int *col, const double *va
             x[i] = x[i] + alpha * pi;
             const double ri = r[i] + na * si;
             r[i] = ri;
-            const double zn = precond ? ri * dinv[i] : ri;
-            z[i] = zn;
-            acc1[i % T] += ri * zn;
+            z[i] = precond ? ri * dinv[i] : ri;
         }
-        for (int b = 0; b < G; ++b) part_b[b] = block_sum(acc1 + (size_t)b * BLK);
+        rz_partials_pairs(n, G, r, z, part_b);                      /* two rows per lane and step, like cg_xr_kernel */
     }
     if (!done) {
         rz_last = reduce1(part_b, G);                                                          /* cg_tail_kernel */
@@ -534,9 +531,9 @@ void orc_dev_xr(int n, int vec_grid, double *r, const double *Ap, const double *
 void orc_dev_cg1_update(int n, int vec_grid, double *x, double *r, double *p, double *sv, double *z, const double *w,
                         const double *dinv, int precond, double alpha, double beta, int first, double *rz_local)
 {
-    const int G = vec_grid, T = G * BLK;
+    const int G = vec_grid;
     const double na = -alpha;
-    double *acc = (double *)calloc((size_t)T, sizeof(double)), *part = (double *)calloc((size_t)G, sizeof(double));
+    double *part = (double *)calloc((size_t)G, sizeof(double));
     for (int i = 0; i < n; ++i) {
         const double zi = z[i], wi = w[i];
         const double pi = first ? zi : zi + beta * p[i];
@@ -546,11 +543,9 @@ void orc_dev_cg1_update(int n, int vec_grid, double *x, double *r, double *p, do
         x[i] = x[i] + alpha * pi;
         const double ri = r[i] + na * si;
         r[i] = ri;
-        const double zn = precond ? ri * dinv[i] : ri;
-        z[i] = zn;
-        acc[i % T] += ri * zn;
+        z[i] = precond ? ri * dinv[i] : ri;
     }
-    for (int b = 0; b < G; ++b) part[b] = block_sum(acc + (size_t)b * BLK);
+    rz_partials_pairs(n, G, r, z, part);                            /* two rows per lane and step, like cg_xr_kernel */
     *rz_local = reduce1(part, G);
-    free(acc); free(part);
+    free(part);
 }

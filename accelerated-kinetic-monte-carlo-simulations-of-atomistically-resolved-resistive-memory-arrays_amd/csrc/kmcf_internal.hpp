@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -260,12 +261,25 @@ struct kmcf_kstate {
 void kmcf_sell_free(kmcf_matrix *m);       // frees the row-per-lane layout (kmcf_spmv.hip)
 void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *col, std::vector<int> &perm, std::vector<int> &cuts);
 
-// grid of the CG's vector kernels (= r.z / b.b partials): 8 blocks per CU at most, one partial per block
+// grid of the CG's vector kernels (= r.z / b.b partials): 8 blocks per CU at most, one partial per block.  One step of
+// two rows per lane where that fits (KMCF_VEC_ROWS rows per lane, default 2): the kernels request a block's first
+// step together with its scalars, so with a single step a block's life is ONE memory round trip (a rank's eighth of
+// the 40 nm matrix: update kernel 7.2 us with two steps per lane).
+// KMCF_DEVICE_SHARE = s: s ranks share this GPU (rehearsals of an N-rank run on fewer GPUs): every grid that is sized to
+// fill the chip takes 1/s of it, so that the ranks' kernels -- which wait for each other on the device -- are resident
+// together (two whole-chip grids of waiting blocks on one GPU starve each other: seen as all-reduce time-outs at 40 nm)
+inline int kmcf_device_share()
+{
+    static const int s = getenv("KMCF_DEVICE_SHARE") ? std::max(1, atoi(getenv("KMCF_DEVICE_SHARE"))) : 1;
+    return s;
+}
+
 inline int kmcf_vec_grid(int n)
 {
-    int64_t g = ((int64_t)n + KMCF_BLOCK * 4 - 1) / (KMCF_BLOCK * 4);
+    static const int rows = getenv("KMCF_VEC_ROWS") ? std::max(2, atoi(getenv("KMCF_VEC_ROWS"))) : 2;
+    int64_t g = ((int64_t)n + KMCF_BLOCK * rows - 1) / (KMCF_BLOCK * rows);
     if (g < 1) g = 1;
-    if (g > KMCF_MAX_PARTIALS) g = KMCF_MAX_PARTIALS;
+    if (g > KMCF_MAX_PARTIALS / kmcf_device_share()) g = KMCF_MAX_PARTIALS / kmcf_device_share();
     return (int)g;
 }
 

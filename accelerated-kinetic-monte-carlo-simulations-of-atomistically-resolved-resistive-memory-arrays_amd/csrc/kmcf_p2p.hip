@@ -272,7 +272,7 @@ int kmcf_p2p_create(kmcf_comm *c)
     KMCF_HIP(hipMemset(w->d_ctr, 0, 4 * sizeof(unsigned int)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_err), sizeof(int), hipHostMallocDefault));
     *w->h_err = 0;
-    double ms = 2000.0;
+    double ms = 10000.0;                               // (ranks may enter a solve seconds apart: set-up, IO)
     if (const char *e = getenv("KMCF_P2P_TIMEOUT_MS")) ms = atof(e);
     int khz = 0;                                       // wall_clock64() tick rate of this device
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;

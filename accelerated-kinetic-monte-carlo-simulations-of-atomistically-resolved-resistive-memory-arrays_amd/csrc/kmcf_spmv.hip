@@ -971,7 +971,7 @@ int window_grid(kmcf_matrix *m, int which)
     int cus = 0;
     const int per_cu = window_dispatch_any(m, which, false, true, false);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->comm->device) != hipSuccess) cus = 0;
-    const int resident = per_cu * cus;
+    const int resident = per_cu * cus / kmcf_device_share();
     int g = grid_for(m->n_tiles, 1);
     if (resident >= 8 && g > resident) g = resident / 8 * 8;
     return g;
@@ -982,7 +982,7 @@ int sell_grid(kmcf_matrix *m)
     int cus = 0;
     const int per_cu = sell_dispatch_any(m, false, true, false);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->comm->device) != hipSuccess) cus = 0;
-    const int resident = per_cu * cus;
+    const int resident = per_cu * cus / kmcf_device_share();
     int g = grid_for(m->n_sell_tiles, 1);
     if (resident >= 8 && g > resident) g = resident / 8 * 8;
     return g;

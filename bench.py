@@ -53,8 +53,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path"
-    if args.transport == "p2p-only" and torch.cuda.device_count() <= local_rank:
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks share a GPU
+    if args.transport == "p2p-only" and torch.cuda.device_count() < world:
+        # rehearsal: several ranks share a GPU; their chip-filling grids take a share each (kmcf_internal.hpp)
+        os.environ.setdefault("KMCF_DEVICE_SHARE", str((world + torch.cuda.device_count() - 1) // max(torch.cuda.device_count(), 1)))
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         # gloo only carries the 256-byte RCCL bootstrap id, barriers and the max-over-ranks
@@ -122,6 +124,7 @@ def main():
     def timed_solve(steps, warmup):
         r, x, dinv = fresh_vectors()
         if warmup > 0:
+            barrier()            # (ranks enter a solve together: its device-side waits are bounded, KMCF_P2P_TIMEOUT_MS)
             S.conjugate_gradient_jacobi(mat, r, x, dinv, tol, 10 ** 9, fixed_iters=warmup)
         r, x, dinv = fresh_vectors()
         barrier()

@@ -18,6 +18,7 @@
 // vector passes = 88 B/row (the reference's op sequence: 144 B/row).
 #include <chrono>
 #include <cmath>
+#include <cstring>
 
 #include "kmcf_p2p_dev.hpp"
 
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
     double *__restrict__ z /* in: z, out: next z (SpMV input) */, const double *__restrict__ w,
     const double *__restrict__ dinv, part_ref pgamma, part_ref pdelta, part_ref pbb, kmcf_scalars *__restrict__ S,
     int parity, int first, double tol2, int check_tol, double *__restrict__ part_rz, kmcf_p2p_dev pd, u64 seq_red,
-    u64 seq_ack, u64 seq_put)
+    u64 seq_ack, u64 seq_put, int ar_inside)
 {
     __shared__ double lds[3][4];
     __shared__ double red[4];
@@ -511,7 +512,15 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg1_update_kernel(
     double gamma, delta, bsum;
     reduce_partials3(pgamma, pdelta, pbb, first != 0, lds, gamma, delta, bsum);
     if (done) return;
-    if (P2P) {
+    if (P2P && !ar_inside) {
+        // the all-reduce ran in a kernel of its own (pgamma ... hold the reduced values): acknowledgement and the wait
+        // for the landing buffers only
+        if (blockIdx.x == 0 && t >= 64 && t < 64 + pd.n_nb) store_release_system(pd.ack_ptr[t - 64], seq_ack);
+        if (t >= 64 && t < 64 + pd.n_nb && seq_put > 2) wait_ge(&pd.acks[(t - 64) * P2P_FS], seq_put - 2, pd.timeout, pd.d_err, pd.h_err, 5);
+        __syncthreads();
+        if (__hip_atomic_load(pd.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    }
+    if (P2P && ar_inside) {
         const int rpar = (int)(seq_red & 1);
         if (blockIdx.x == 0) {
             if (t < pd.P) {
@@ -654,6 +663,10 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
     // are counted per LAUNCH here and set back to per EXECUTED exchange after the loop (kernels behind the stop return
     // at once, on every rank alike): the protocol's parities and acknowledgement windows need dense numbers.
     const bool fused = multi && c->nranks > 1 && kmcf_p2p_direct(m);
+    // where the all-reduce of a fused iteration runs: inside the update kernel (every block waits for the P flags: one
+    // kernel fewer; right when every rank has a GPU of its own) or in a 1-block kernel in front of it (KMCF_P2P_AR=split:
+    // ranks SHARING a GPU -- rehearsals -- otherwise fill it with waiting blocks); bench.py times both and keeps the faster
+    const bool ar_inside = !(getenv("KMCF_P2P_AR") && strcmp(getenv("KMCF_P2P_AR"), "split") == 0);
     const bool p2p_red = multi && c->nranks > 1 && c->p2p_active;
     const u64 red0 = p2p_red ? kmcf_p2p_red_seq(c) : 0, halo0 = fused ? *kmcf_p2p_halo_seq(m, 0) : 0;
 
@@ -669,10 +682,22 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             const int parity = k & 1, first = (k == 1) ? 1 : 0;
             KMCF_TRY(kmcf_spmv_device(m, true, true, fused ? 1 : 0));  // w = A z, delta partials
             if (fused) {
-                const u64 sr = kmcf_p2p_next_red_seq(c), sh = *kmcf_p2p_halo_seq(m, 0);
-                cg1_update_kernel<PRECOND, true><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
-                                                                            pg_loc, pd_loc, pb_loc, S, parity, first, tol2, check_tol,
-                                                                            m->d_part_b, kmcf_p2p_dev_of(m), sr, sh, sh + 1);
+                const u64 sh = *kmcf_p2p_halo_seq(m, 0);
+                if (ar_inside) {
+                    const u64 sr = kmcf_p2p_next_red_seq(c);
+                    cg1_update_kernel<PRECOND, true><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
+                                                                                pg_loc, pd_loc, pb_loc, S, parity, first, tol2, check_tol,
+                                                                                m->d_part_b, kmcf_p2p_dev_of(m), sr, sh, sh + 1, 1);
+                } else {
+                    // KMCF_P2P_AR=split: finalize + exchange in a 1-block kernel of its own, the update kernel reads the sums
+                    const kmcf_part4 parts[3] = {{{pg_loc.p[0], pg_loc.p[1], pg_loc.p[2], pg_loc.p[3]}, {pg_loc.n[0], pg_loc.n[1], pg_loc.n[2], pg_loc.n[3]}},
+                                                 {{pd_loc.p[0], pd_loc.p[1], pd_loc.p[2], pd_loc.p[3]}, {pd_loc.n[0], pd_loc.n[1], pd_loc.n[2], pd_loc.n[3]}},
+                                                 {{pb_loc.p[0], pb_loc.p[1], pb_loc.p[2], pb_loc.p[3]}, {pb_loc.n[0], pb_loc.n[1], pb_loc.n[2], pb_loc.n[3]}}};
+                    KMCF_TRY(kmcf_p2p_allreduce_parts(c, parts, 3, S, 1));
+                    cg1_update_kernel<PRECOND, true><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap, m->d_dinv,
+                                                                                pg, pd, pb, S, parity, first, tol2, check_tol, m->d_part_b,
+                                                                                kmcf_p2p_dev_of(m), 0, sh, sh + 1, 0);
+                }
                 KMCF_HIP(hipGetLastError());
                 *kmcf_p2p_halo_seq(m, 1) = sh + 1;                      // the halo of the next SpMV is put
                 continue;
@@ -691,7 +716,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             }
             cg1_update_kernel<PRECOND, false><<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_r, m->d_pd, m->d_s, m->d_p, m->d_Ap,
                                                                          m->d_dinv, pg, pd, pb, S, parity, first, tol2,
-                                                                         check_tol, m->d_part_b, kmcf_p2p_dev{}, 0, 0, 0);
+                                                                         check_tol, m->d_part_b, kmcf_p2p_dev{}, 0, 0, 0, 0);
             KMCF_HIP(hipGetLastError());
         }
         launched += chunk;

@@ -486,7 +486,8 @@ int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land
 
 bool kmcf_p2p_direct(const kmcf_matrix *m)
 {
-    static const bool off = getenv("KMCF_P2P_DIRECT") && atoi(getenv("KMCF_P2P_DIRECT")) == 0;
+    const char *e = getenv("KMCF_P2P_DIRECT");              // (read per call: bench.py times the protocols against each other)
+    const bool off = e && atoi(e) == 0;
     const kmcf_comm *c = m->comm;
     // long rows and the tunnel sub-block read the halo behind p_local: they keep the copying protocol
     return !off && c->p2p_active && c->nranks > 1 && m->p2p && m->p2p->d_put_row && m->n_long_items == 0 && !m->sub;

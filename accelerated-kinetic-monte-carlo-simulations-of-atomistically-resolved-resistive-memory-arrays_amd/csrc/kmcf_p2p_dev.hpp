@@ -19,6 +19,10 @@ constexpr size_t P2P_OFF_BUMP = P2P_OFF_G_ACK + P2P_MAXR * 128;
 
 typedef unsigned long long u64;
 
+#ifndef KMCF_P2P_SLEEP
+#define KMCF_P2P_SLEEP 8             // s_sleep argument between two polls of a flag (units of 64 clocks)
+#endif
+
 struct kmcf_p2p_dev;
 
 struct kmcf_p2p {
@@ -113,7 +117,7 @@ __device__ __forceinline__ bool wait_ge(const u64 *p, u64 v, long long timeout, 
             __hip_atomic_store(h_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(KMCF_P2P_SLEEP);
     }
     return true;
 }

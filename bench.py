@@ -141,26 +141,43 @@ def main():
     # (rank 0 decides).  A transport that fails its trial (a bounded wait of the peer-to-peer protocol expiring on
     # every rank) is reported and not used.
     transports = None
-    if world > 1 and comm.transport() == "p2p (bootstrapped over rccl)":
+    P2P_MODES = {"p2p": {"KMCF_P2P_DIRECT": "1", "KMCF_P2P_AR": "fused"},        # 3 kernels per iteration, exchanges inside them
+                 "p2p-split": {"KMCF_P2P_DIRECT": "1", "KMCF_P2P_AR": "split"},  # all-reduce in a 1-block kernel of its own
+                 "p2p-staged": {"KMCF_P2P_DIRECT": "0"}}                         # put / wait-copy kernels on a second stream
+
+    def set_mode(name):
+        for k, v in P2P_MODES.get(name, {}).items():
+            os.environ[k] = v
+
+    if world > 1 and comm.transport().startswith("p2p"):
+        has_rccl = comm.transport() == "p2p (bootstrapped over rccl)"
         transports = {}
-        for name, use in (("rccl", 0), ("p2p", 1)):
+        for name in (["rccl"] if has_rccl else []) + list(P2P_MODES):
             try:
-                comm.select_transport(use)
+                if has_rccl:
+                    comm.select_transport(0 if name == "rccl" else 1)
+                set_mode(name)
                 t_trial, st_trial = timed_solve(min(args.steps, 20), 3)
                 transports[name] = {"trial_ms_per_step": round(t_trial * 1e3 / min(args.steps, 20), 5),
                                     "trial_rz": st_trial["rz"]}
             except km.lib.KmcfError as e:
                 transports[name] = {"error": str(e)[:200]}
-        # the two transports run the same recurrence (the dots differ only in the order the ranks' partial sums are
-        # added): a residual that disagrees beyond rounding means the peer-to-peer exchange delivered wrong data
-        if all("trial_rz" in v for v in transports.values()) and len(transports) == 2:
-            a, b = transports["rccl"]["trial_rz"], transports["p2p"]["trial_rz"]
-            if not (abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1e-300)):
-                transports["p2p"] = {"error": "residual after the trial solve differs from the RCCL transport's: %r vs %r" % (b, a)}
+        # every candidate runs the same recurrence (the dots differ only in the order the ranks' partial sums are
+        # added, and only on RCCL): a residual that disagrees beyond rounding means an exchange delivered wrong data
+        ref = next((v["trial_rz"] for v in transports.values() if "trial_rz" in v), None)
+        for name, v in transports.items():
+            if "trial_rz" in v and not (abs(v["trial_rz"] - ref) <= 1e-6 * max(abs(ref), abs(v["trial_rz"]), 1e-300)):
+                transports[name] = {"error": "residual after the trial solve differs: %r vs %r" % (v["trial_rz"], ref)}
         ok = {k: v["trial_ms_per_step"] for k, v in transports.items() if "trial_ms_per_step" in v}
-        pick = torch.tensor([1 if ("p2p" in ok and ok["p2p"] <= ok.get("rccl", 1e30)) else 0])
-        dist.broadcast(pick, src=0)
-        comm.select_transport(int(pick.item()))
+        names = list(transports)
+        best = min(ok, key=ok.get) if ok else names[0]
+        pick = torch.tensor([names.index(best)])
+        dist.broadcast(pick, src=0)                 # rank 0 decides
+        best = names[int(pick.item())]
+        if has_rccl:
+            comm.select_transport(0 if best == "rccl" else 1)
+        set_mode(best)
+        transports["picked"] = best
     # K steps per solve, bracketed by barriers; `repeats` such solves, the median one is reported (all are listed)
     runs = [timed_solve(args.steps, args.warmup if i == 0 else 0) for i in range(max(1, args.repeats))]
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
@@ -294,7 +311,8 @@ def main():
         if transports is not None:
             diag["transports"] = transports
         used_p2p = comm.transport().startswith("p2p")
-        for name, use in ((("rccl", 0), ("p2p", 1)) if transports is not None else ((comm.transport(), None),)):
+        has_rccl = transports is not None and "rccl" in transports
+        for name, use in ((("rccl", 0), ("p2p", 1)) if has_rccl else ((comm.transport(), None),)):
             if transports is not None and "error" in transports.get(name, {}):
                 continue
             try:
@@ -307,7 +325,7 @@ def main():
                 diag[name] = d_t
             except km.lib.KmcfError as e:
                 diag[name] = {"error": str(e)[:200]}
-        if transports is not None:
+        if has_rccl:
             comm.select_transport(1 if used_p2p else 0)
 
     # HBM traffic of that kernel from rocprofv3 PMC runs (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
@@ -373,7 +391,8 @@ def main():
             "repeats": len(runs), "ms_per_step_all": all_ms, "ms_per_step_min": min(all_ms), "ms_per_step_max": max(all_ms),
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": d["name"], "rows": n_if, "nnz": nnz_tot, "sites": d["N"],
-                       "partition": "1-D block rows x %d" % world, "transport": comm.transport(), "solver": "jacobi-pcg fixed %d iterations" % args.steps,
+                       "partition": "1-D block rows x %d" % world,
+                       "transport": comm.transport() + (" / " + transports["picked"] if transports else ""), "solver": "jacobi-pcg fixed %d iterations" % args.steps,
                        "halo_cols_rank0": info["halo_cols"], "neighbours_rank0": info["number_of_neighbours"],
                        "setup_s": round(t_setup, 2), "device_ms_cg": round(st["ms_solve"], 3)},
             "roofline": roofline,

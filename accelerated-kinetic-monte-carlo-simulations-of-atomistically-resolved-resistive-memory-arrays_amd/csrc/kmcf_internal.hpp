@@ -318,6 +318,20 @@ struct kmcf_subop {
     long long nnz = 0;
     size_t cap_mask = 0, cap_val = 0, cap_rows = 0, cap_x = 0, cap_voff = 0;
     int grid = 0;                            // blocks of the operator kernel = partials it writes
+    // Dense symmetric storage (kmcf_tstate.hip: sub_symm_kernel), chosen per assembly for one rank when the block is
+    // more than half full (the vacancy-vacancy block of a large device is ~100 % dense): the upper block triangle
+    // as 64 x 64 tiles of f64 (zeros where the pattern has no entry), diagonal tiles complete.  Half the bytes of the
+    // packed full block per application; every tile serves its block row (row sums) and, transposed out of LDS, its
+    // block column (column sums); partial sums are written per strip / tile and added in a fixed order.
+    bool dense = false;
+    int nb = 0;                              // ceil(n_glob / 64)
+    int n_strips = 0;
+    long long n_tiles = 0;
+    double *d_tiles = nullptr;               // n_tiles x 4096
+    int4 *d_strips = nullptr;                // (block row I, first block column J0, tiles, first tile index)
+    int *d_strip_first = nullptr;            // nb + 1: first strip of every block row
+    double *d_rowpart = nullptr, *d_colpart = nullptr;   // 2 x 64 per strip / 2 x 64 per tile (the power pass needs two sums)
+    size_t cap_tiles = 0, cap_strips = 0, cap_sf = 0, cap_rowpart = 0, cap_colpart = 0;
 };
 
 // ---------------------------------------------------------------- internal entry points

@@ -654,6 +654,191 @@ __global__ __launch_bounds__(KMCF_BLOCK) void copy_pdisp_kernel(int n_atoms_in_m
         if (!(acls[a] & 1)) site_power[atom_site[a]] = -1 * alpha * pdisp[a + 2];
 }
 
+
+// ---------------------------------------------------------------- dense symmetric sub-block (kmcf_subop::dense)
+// Tile (I, J), J >= I, of the upper block triangle: 64 x 64 f64, row-major, at tile index I nb - I (I - 1) / 2 + (J - I).
+__host__ __device__ inline long long symm_tile_index(int nb, int I, int J) { return (long long)I * nb - (long long)I * (I - 1) / 2 + (J - I); }
+
+constexpr int SYM_LD = 65;                                   // LDS row stride (doubles): row- AND column-wise reads conflict-free
+constexpr int SYM_WAVE_DOUBLES = 64 * SYM_LD + 256;          // tile + four 64-vectors per wave
+
+// Values of the upper tiles (populate_T_tunnel_dist2 on the pairs of the tile; 0 where the pattern has no entry, on
+// the diagonal -- set afterwards -- and past the last point).  A wave per strip, lane = column, rows one by one.
+__global__ __launch_bounds__(KMCF_BLOCK) void tunnel_dense_fill_kernel(
+    int n_strips, const int4 *__restrict__ strips, int n_glob, const int *__restrict__ tinfo, const double *__restrict__ tx,
+    const double *__restrict__ ty, const double *__restrict__ tz, const double *__restrict__ tcb, double nn_dist, double tol,
+    double m_e, double V0, double *__restrict__ tiles)
+{
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < n_strips; s += gridDim.x * 4) {
+        const int4 st = strips[s];
+        for (int q = 0; q < st.z; ++q) {
+            const int J = st.y + q, j = 64 * J + lane;
+            const bool jin = j < n_glob;
+            const double xj = jin ? tx[j] : 0.0, yj = jin ? ty[j] : 0.0, zj = jin ? tz[j] : 0.0, cbj = jin ? tcb[j] : 0.0;
+            const int fj = jin ? tinfo[j] : 0;
+            double *tile = tiles + ((size_t)st.w + q) * 4096;
+            for (int r = 0; r < 64; ++r) {
+                const int i = 64 * st.x + r;
+                double v = 0.0;
+                if (i < n_glob && jin && i != j) {
+                    bool c2t;
+                    const double cbi = tcb[i];
+                    const double d = dist3(tx[i], ty[i], tz[i], xj, yj, zj);
+                    if (d > nn_dist && tunnel_pair(tinfo[i], fj, cbi, cbj, tol, &c2t)) v = wkb_value(d, cbi, cbj, c2t, m_e, V0);
+                }
+                tile[r * 64 + lane] = v;
+            }
+        }
+    }
+}
+
+// One pass over the upper tiles.  MODE 0: parts of y = S x (x: the gathered sub-vector).  MODE 1: parts of the
+// dissipated-power sums a_i = sum_j ineg(v_ij, m_i, m_j) m_j, b_i = sum_j ineg(v_ij, m_i, m_j) (x: the potentials of the
+// tunnel points; the diagonal is skipped).  A wave per strip of tiles of one block row: the tile goes global ->
+// registers -> LDS (the NEXT tile's loads are in flight while this one is used); lane r adds row r's products
+// column by column (its row sum runs on through the strip's tiles), lane c adds column c's products row by row
+// (the tile's contribution to block row J by symmetry; not for diagonal tiles, which are stored complete).
+template <int MODE>
+__global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_kernel(int n_strips, const int4 *__restrict__ strips, const double *__restrict__ tiles,
+                                                              const double *__restrict__ x, double Vd, double *__restrict__ rowpart,
+                                                              double *__restrict__ colpart)
+{
+    extern __shared__ double sym_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *T = sym_lds + (size_t)wv * SYM_WAVE_DOUBLES;
+    double *xI = T + 64 * SYM_LD, *xJ = xI + 64;
+    for (int s = blockIdx.x * 4 + wv; s < n_strips; s += gridDim.x * 4) {
+        const int4 st = strips[s];
+        const int I = st.x;
+        xI[lane] = x[64 * I + lane];
+        double ra = 0.0, rb = 0.0;
+        typedef double dvec2 __attribute__((ext_vector_type(2)));
+        dvec2 reg[32];
+        {
+            const dvec2 *src = reinterpret_cast<const dvec2 *>(tiles + (size_t)st.w * 4096);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) reg[k] = __builtin_nontemporal_load(src + k * 64 + lane);
+        }
+        for (int q = 0; q < st.z; ++q) {
+            const int J = st.y + q;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {                   // element pair k 64 + lane = row 2 k + (lane >> 5), columns 2 (lane & 31), + 1
+                const int r = 2 * k + (lane >> 5), c = 2 * (lane & 31);
+                T[r * SYM_LD + c] = reg[k].x;
+                T[r * SYM_LD + c + 1] = reg[k].y;
+            }
+            xJ[lane] = x[64 * J + lane];
+            if (q + 1 < st.z) {
+                const dvec2 *src = reinterpret_cast<const dvec2 *>(tiles + ((size_t)st.w + q + 1) * 4096);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) reg[k] = __builtin_nontemporal_load(src + k * 64 + lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool diag = J == I;
+            if (MODE == 0) {
+#pragma unroll 8
+                for (int c = 0; c < 64; ++c) ra += T[lane * SYM_LD + c] * xJ[c];
+                if (!diag) {
+                    double ca = 0.0;
+#pragma unroll 8
+                    for (int r = 0; r < 64; ++r) ca += T[r * SYM_LD + lane] * xI[r];
+                    colpart[((size_t)st.w + q) * 64 + lane] = ca;
+                }
+            } else {
+                const double mr = xI[lane];
+                for (int c = 0; c < 64; ++c) {
+                    if (diag && c == lane) continue;
+                    const double mc = xJ[c];
+                    const double ig = ineg_of(T[lane * SYM_LD + c], mr, mc, Vd);
+                    ra += ig * mc;
+                    rb += ig;
+                }
+                if (!diag) {
+                    const double mj = xJ[lane];
+                    double ca = 0.0, cb = 0.0;
+                    for (int r = 0; r < 64; ++r) {
+                        const double mi = xI[r];
+                        const double ig = ineg_of(T[r * SYM_LD + lane], mj, mi, Vd);
+                        ca += ig * mi;
+                        cb += ig;
+                    }
+                    colpart[((size_t)st.w + q) * 128 + lane] = ca;
+                    colpart[((size_t)st.w + q) * 128 + 64 + lane] = cb;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (MODE == 0) rowpart[(size_t)s * 64 + lane] = ra;
+        else { rowpart[(size_t)s * 128 + lane] = ra; rowpart[(size_t)s * 128 + 64 + lane] = rb; }
+    }
+}
+
+// Adds the parts in a fixed order -- block columns K < B (column sums of tiles (K, B), K ascending), then the strips of
+// block row B -- into y[rows[i]] (MODE 0; rows == nullptr: y[i]) or psum / isum (MODE 1); fused p.Ap partial (MODE 0).
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_reduce_kernel(int n_glob, int nb, const int *__restrict__ strip_first,
+                                                                     const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                                     const int *__restrict__ rows, const double *__restrict__ p,
+                                                                     double *__restrict__ y, double *__restrict__ y2, double *__restrict__ part,
+                                                                     const kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    constexpr int W = MODE == 0 ? 64 : 128;
+    const int i = blockIdx.x * KMCF_BLOCK + threadIdx.x;
+    const int B = i >> 6, l = i & 63;
+    double dot = 0.0;
+    if (i < n_glob) {
+        double a = 0.0, b = 0.0;
+        for (int K = 0; K < B; ++K) {
+            const size_t t = (size_t)symm_tile_index(nb, K, B);
+            a += colpart[t * W + l];
+            if (MODE == 1) b += colpart[t * W + 64 + l];
+        }
+        for (int s = strip_first[B]; s < strip_first[B + 1]; ++s) {
+            a += rowpart[(size_t)s * W + l];
+            if (MODE == 1) b += rowpart[(size_t)s * W + 64 + l];
+        }
+        const int r = rows ? rows[i] : i;
+        if (MODE == 0) {
+            y[r] += a;
+            if (DOT) dot += p[r] * a;
+        } else {
+            y[r] += a;
+            y2[r] += b;
+        }
+    }
+    if (DOT) {
+        const double t = block_sum4(dot, lds4);
+        if (threadIdx.x == 0) part[blockIdx.x] = t;
+    }
+}
+
+// tdiag = -(row sums), the diagonal entries of the diagonal tiles (calc_diagonal_T_tunnel, :669-689)
+__global__ __launch_bounds__(KMCF_BLOCK) void symm_set_diag_kernel(int n_glob, int nb, const double *__restrict__ rowsum, double *__restrict__ tdiag,
+                                                                   double *__restrict__ tiles)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_glob; i += gridDim.x * blockDim.x) {
+        const double d = -rowsum[i];
+        tdiag[i] = d;
+        const int B = i >> 6, l = i & 63;
+        tiles[(size_t)symm_tile_index(nb, B, B) * 4096 + l * 64 + l] = d;
+    }
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void fill_kernel(int n, double *__restrict__ a, double v)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
+}
+
+__global__ __launch_bounds__(KMCF_BLOCK) void gather_tunnel_pot_kernel(int n_glob, const int *__restrict__ tidx, const double *__restrict__ m,
+                                                                       double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_glob; i += gridDim.x * blockDim.x) out[i] = m[tidx[i] + 2];
+}
+
 template <typename T>
 int ensure(T **d, size_t *cap, size_t need)
 {
@@ -685,7 +870,8 @@ extern "C" int kmcf_tstate_destroy(kmcf_tstate *t)
         void *ptrs[] = {t->d_atom_site, t->d_site_is_atom, t->d_ax, t->d_ay, t->d_az, t->d_acb, t->d_ael, t->d_ach, t->d_acls,
                         t->d_cls_col, t->d_col_node, t->d_diag_pos, t->d_ground, t->d_inv_perm, t->d_diag, t->d_diag_tot, t->d_rhs,
                         t->d_tflag, t->d_blk, t->d_tidx, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->d_rowcnt, t->d_tdiag,
-                        t->sub.d_rows, t->sub.d_mask, t->sub.d_voff, t->sub.d_val, t->sub.d_xsub, t->d_pdisp, t->d_scal, t->d_err};
+                        t->sub.d_rows, t->sub.d_mask, t->sub.d_voff, t->sub.d_val, t->sub.d_xsub, t->d_pdisp, t->d_scal, t->d_err,
+                        t->sub.d_tiles, t->sub.d_strips, t->sub.d_strip_first, t->sub.d_rowpart, t->sub.d_colpart};
         for (void *p : ptrs)
             if (p) hipFree(p);
         if (t->h_pin) hipHostFree(t->h_pin);
@@ -873,6 +1059,69 @@ extern "C" int kmcf_tstate_atom_sites(const kmcf_tstate *t, int *h_atom_site)
     return KMCF_OK;
 }
 
+
+// launches of the dense symmetric operator (dynamic LDS beyond 64 KB needs the attribute once per kernel)
+template <int MODE>
+static int symm_launch(kmcf_subop &sb, const double *x, double Vd, hipStream_t st)
+{
+    static bool attr_done = false;
+    const size_t lds = (size_t)4 * SYM_WAVE_DOUBLES * sizeof(double);
+    if (!attr_done) {
+        KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sub_symm_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));
+    sub_symm_kernel<MODE><<<grid, KMCF_BLOCK, lds, st>>>(sb.n_strips, sb.d_strips, sb.d_tiles, x, Vd, sb.d_rowpart, sb.d_colpart);
+    KMCF_HIP(hipGetLastError());
+    return KMCF_OK;
+}
+
+// strips, tiles, values, diagonal of the dense symmetric storage (one rank; after the tunnel points are known)
+static int symm_setup(kmcf_tstate *t)
+{
+    kmcf_subop &sb = t->sub;
+    hipStream_t st = t->comm->stream;
+    const kmcf_current_params_t *p = &t->par;
+    const int n_t = sb.n_glob, nb = (n_t + 63) / 64;
+    sb.nb = nb;
+    sb.n_tiles = (long long)nb * (nb + 1) / 2;
+    int strip_len = 16;
+    if (const char *e = getenv("KMCF_SUB_STRIP")) strip_len = std::max(1, atoi(e));
+    std::vector<int4> strips;
+    std::vector<int> first((size_t)nb + 1, 0);
+    for (int I = 0; I < nb; ++I) {
+        first[I] = (int)strips.size();
+        for (int J = I; J < nb; J += strip_len)
+            strips.push_back(make_int4(I, J, std::min(strip_len, nb - J), (int)symm_tile_index(nb, I, J)));
+    }
+    first[nb] = (int)strips.size();
+    KMCF_CHECK(sb.n_tiles < (long long)INT32_MAX, KMCF_ERR_ARG, "tunnel block of %d points: tile index exceeds int32", n_t);
+    sb.n_strips = (int)strips.size();
+    KMCF_TRY(ensure(&sb.d_tiles, &sb.cap_tiles, (size_t)sb.n_tiles * 4096));
+    KMCF_TRY(ensure(&sb.d_strips, &sb.cap_strips, strips.size()));
+    KMCF_TRY(ensure(&sb.d_strip_first, &sb.cap_sf, first.size()));
+    KMCF_TRY(ensure(&sb.d_rowpart, &sb.cap_rowpart, (size_t)sb.n_strips * 128));
+    KMCF_TRY(ensure(&sb.d_colpart, &sb.cap_colpart, (size_t)sb.n_tiles * 128));
+    KMCF_HIP(hipMemcpyAsync(sb.d_strips, strips.data(), strips.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+    KMCF_HIP(hipMemcpyAsync(sb.d_strip_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    KMCF_HIP(hipStreamSynchronize(st));                            // (the host vectors go out of scope)
+    const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));
+    tunnel_dense_fill_kernel<<<grid, KMCF_BLOCK, 0, st>>>(sb.n_strips, sb.d_strips, n_t, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist,
+                                                         p->tol, p->m_e, p->V0, sb.d_tiles);
+    KMCF_HIP(hipGetLastError());
+    // diagonal = -(row sums): one application to the vector of ones (the diagonal entries are still 0)
+    fill_kernel<<<grid1d(64 * nb), KMCF_BLOCK, 0, st>>>(64 * nb, sb.d_xsub, 1.0);
+    KMCF_HIP(hipMemsetAsync(t->d_tdiag, 0, (size_t)n_t * sizeof(double), st));
+    KMCF_TRY(symm_launch<0>(sb, sb.d_xsub, 0.0, st));
+    sub_symm_reduce_kernel<0, false><<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart, nullptr, nullptr,
+                                                                        t->d_tdiag, nullptr, nullptr, nullptr, 0);
+    symm_set_diag_kernel<<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_tiles);
+    KMCF_HIP(hipMemsetAsync(sb.d_xsub, 0, (size_t)64 * nb * sizeof(double), st));      // the pad behind the last point stays 0
+    KMCF_HIP(hipGetLastError());
+    sb.grid = (n_t + KMCF_BLOCK - 1) / KMCF_BLOCK;                  // partials of the reduce kernel
+    return KMCF_OK;
+}
+
 static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int *d_site_charge, const double *d_site_CB_edge,
                             const int *d_metals, int num_metals, const kmcf_current_params_t *p)
 {
@@ -936,7 +1185,7 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
     KMCF_TRY(ensure(&sb.d_voff, &sb.cap_voff, (size_t)ns + 2));
     KMCF_HIP(hipMemsetAsync(sb.d_voff, 0, ((size_t)ns + 2) * sizeof(long long), st));
     KMCF_TRY(ensure(&sb.d_mask, &sb.cap_mask, (size_t)ns * ng + 1));
-    KMCF_TRY(ensure(&sb.d_xsub, &sb.cap_x, (size_t)n_t + 256));          // + 256: the 4-group unroll reads x_sub[j + 192] only when set
+    KMCF_TRY(ensure(&sb.d_xsub, &sb.cap_x, (size_t)n_t + 320));          // + 256: the 4-group unroll reads x_sub[j + 192] only when set
     KMCF_TRY(ensure(&t->d_rowcnt, &t->cap_rowcnt, (size_t)ns + 1));
     KMCF_TRY(ensure(&t->d_tdiag, &t->cap_tdiag, (size_t)ns + 1));
     const int wpb = KMCF_BLOCK / 64;
@@ -952,10 +1201,20 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
         KMCF_HIP(hipMemcpyAsync(pin_nnz, sb.d_voff + ns, sizeof(long long), hipMemcpyDeviceToHost, st));
         KMCF_HIP(hipStreamSynchronize(st));
         sb.nnz = *pin_nnz;
-        KMCF_TRY(ensure(&sb.d_val, &sb.cap_val, (size_t)sb.nnz + 64));
-        tunnel_value_kernel<<<wgrid, KMCF_BLOCK, 0, st>>>(ns, sb.row0, ng, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist, p->tol,
-                                                          p->m_e, p->V0, sb.d_mask, sb.d_voff, sb.d_val, t->d_tdiag);
-        KMCF_HIP(hipGetLastError());
+        // storage of the block: dense symmetric tiles for one rank when the block is more than half full (half the bytes
+        // of the packed full block per application), else the bitmap + packed values.  KMCF_SUB_DENSE=0 / 1 overrides.
+        sb.dense = P == 1 && n_t >= 2048 && 2.0 * (double)sb.nnz > (double)n_t * (double)n_t;
+        if (const char *e = getenv("KMCF_SUB_DENSE")) sb.dense = P == 1 && atoi(e) != 0;
+        if (sb.dense) {
+            KMCF_TRY(symm_setup(t));
+        } else {
+            KMCF_TRY(ensure(&sb.d_val, &sb.cap_val, (size_t)sb.nnz + 64));
+            tunnel_value_kernel<<<wgrid, KMCF_BLOCK, 0, st>>>(ns, sb.row0, ng, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist, p->tol,
+                                                              p->m_e, p->V0, sb.d_mask, sb.d_voff, sb.d_val, t->d_tdiag);
+            KMCF_HIP(hipGetLastError());
+        }
+    } else {
+        sb.dense = false;
     }
     // 4. preconditioner and right-hand side
     if (n_loc > 0) {
@@ -985,6 +1244,18 @@ int kmcf_subop_apply(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     KMCF_TRY(kmcf_comm_allgatherv_double(c, sb->d_xsub, sb->counts.data(), sb->displs.data()));
     if (sb->n_loc == 0) return KMCF_OK;
     double *part = m->d_part_a + 3 * KMCF_MAX_PARTIALS;
+    if (sb->dense) {
+        // (skip_if_done: the tile pass is not skipped -- it has no side effect -- the reduce kernel, which adds into Ap, is)
+        KMCF_TRY(symm_launch<0>(*sb, sb->d_xsub, 0.0, st));
+        if (with_dot)
+            sub_symm_reduce_kernel<0, true><<<sb->grid, KMCF_BLOCK, 0, st>>>(sb->n_glob, sb->nb, sb->d_strip_first, sb->d_rowpart, sb->d_colpart,
+                                                                            sb->d_rows, m->d_p, m->d_Ap, nullptr, part, m->d_S, chk);
+        else
+            sub_symm_reduce_kernel<0, false><<<sb->grid, KMCF_BLOCK, 0, st>>>(sb->n_glob, sb->nb, sb->d_strip_first, sb->d_rowpart, sb->d_colpart,
+                                                                             sb->d_rows, m->d_p, m->d_Ap, nullptr, part, m->d_S, chk);
+        KMCF_HIP(hipGetLastError());
+        return KMCF_OK;
+    }
     if (with_dot)
         sub_spmv_kernel<true><<<sb->grid, KMCF_BLOCK, 0, st>>>(sb->n_loc, sb->n_glob, sb->n_groups, sb->d_mask, sb->d_voff, sb->d_val, sb->d_xsub,
                                                               sb->d_rows, m->d_p, m->d_Ap, part, m->d_S, chk);
@@ -1042,8 +1313,14 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
     if (h_tunnel_idx && sb.n_glob) memcpy(h_tunnel_idx, t->h_tidx.data(), (size_t)sb.n_glob * sizeof(int));
     const int ns = sb.n_loc, ng = sb.n_groups;
     if (h_diag && ns) KMCF_HIP(hipMemcpy(h_diag, t->d_tdiag, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
-    if (h_val && sb.nnz) KMCF_HIP(hipMemcpy(h_val, sb.d_val, (size_t)sb.nnz * sizeof(double), hipMemcpyDeviceToHost));   // packed = CSR order
-    if (h_row_ptr || h_col) {
+    std::vector<double> tiles;
+    if (h_val && sb.nnz && sb.dense) {                       // values out of the upper tiles (test-sized blocks)
+        tiles.resize((size_t)sb.n_tiles * 4096);
+        KMCF_HIP(hipMemcpy(tiles.data(), sb.d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost));
+    } else if (h_val && sb.nnz) {
+        KMCF_HIP(hipMemcpy(h_val, sb.d_val, (size_t)sb.nnz * sizeof(double), hipMemcpyDeviceToHost));   // packed = CSR order
+    }
+    if (h_row_ptr || h_col || !tiles.empty()) {
         std::vector<unsigned long long> mk((size_t)ns * ng + 1);
         if (ns) KMCF_HIP(hipMemcpy(mk.data(), sb.d_mask, (size_t)ns * ng * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         int64_t pos = 0;
@@ -1054,6 +1331,10 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
                 while (w) {
                     const int b = __builtin_ctzll(w);
                     if (h_col) h_col[pos] = g * 64 + b;
+                    if (!tiles.empty()) {
+                        const int i = sb.row0 + s, j = g * 64 + b, lo = std::min(i, j), hi = std::max(i, j);
+                        h_val[pos] = tiles[(size_t)symm_tile_index(sb.nb, lo >> 6, hi >> 6) * 4096 + (size_t)(lo & 63) * 64 + (hi & 63)];
+                    }
                     ++pos;
                     w &= w - 1;
                 }
@@ -1109,7 +1390,14 @@ extern "C" int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_elemen
         if (n_loc > 0) {
             power_neighbour_kernel<16><<<grid1d((int64_t)n_loc * 16), KMCF_BLOCK, 0, st>>>(
                 n_loc, m->d_row_ptr, m->d_col, m->d_val, t->d_diag_pos, t->d_col_node, d_atom_virtual_potentials, p->Vd, psum, isum);
-            if (t->sub.n_loc > 0)
+            if (t->sub.n_loc > 0 && t->sub.dense) {
+                kmcf_subop &sb = t->sub;
+                gather_tunnel_pot_kernel<<<grid1d(sb.n_glob), KMCF_BLOCK, 0, st>>>(sb.n_glob, t->d_tidx, d_atom_virtual_potentials, sb.d_xsub);
+                KMCF_TRY(symm_launch<1>(sb, sb.d_xsub, p->Vd, st));
+                sub_symm_reduce_kernel<1, false><<<grid1d(sb.n_glob), KMCF_BLOCK, 0, st>>>(sb.n_glob, sb.nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart,
+                                                                                          sb.d_rows, nullptr, psum, isum, nullptr, nullptr, 0);
+                KMCF_HIP(hipMemsetAsync(sb.d_xsub + sb.n_glob, 0, (size_t)(64 * sb.nb - sb.n_glob) * sizeof(double), st));
+            } else if (t->sub.n_loc > 0)
                 power_tunnel_kernel<<<t->sub.grid, KMCF_BLOCK, 0, st>>>(t->sub.n_loc, t->sub.row0, t->sub.n_groups, t->sub.d_mask, t->sub.d_voff,
                                                                        t->sub.d_val, t->d_tidx, t->sub.d_rows, d_atom_virtual_potentials, p->Vd,
                                                                        psum, isum);

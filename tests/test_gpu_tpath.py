@@ -322,3 +322,77 @@ def test_small_device_multirank(km, oracle, torch, P):
         np.testing.assert_array_equal(o["pw"] == -7.0, pw == -7.0)
         tight = np.r_[0, 1, 2 + np.nonzero(np.isin(T.atom_element[:-1], [TI, N_EL]))[0]]
         assert np.abs(o["v"][tight] - m[tight]).max() <= 2e-6 * np.abs(m).max()
+
+
+@pytest.mark.parametrize("device", ["small", "5nm"])
+def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5, ref5, torch, monkeypatch, device):
+    """The tunnel block stored as dense symmetric 64 x 64 tiles (the upper block triangle once; what a > 50 % dense block
+    of one rank gets, KMCF_SUB_DENSE=1 forces it here) against the bitmap + packed-values storage and the oracle:
+    same values, same diagonal, same operator (to rounding: the two add in different orders), same solve, current and
+    power.  The 40 nm test (tests/test_gpu_fullsize.py) runs this storage at full size through properties."""
+    S = km.solvers
+    if device == "small":
+        d = small_device(seed=7)
+        a = 2.5
+        kw = dict(contact_x_lo=(d["layers"] - 1) * a - 0.1, contact_x_hi=(d["layers"] + 7) * a + 0.1)
+        metals = np.array([TI, N_EL], np.int32)
+        par = dict(PAR)
+        n1, layers, xyz, element, charge, cb = d["n1"], d["layers"], d["xyz"], d["element"], d["charge"], d["cb"]
+        lattice, sigma, kk, nmet = [1, 1, 1], 3.5e-10, 1.0, 2
+    else:
+        d = dev5
+        kw = {}
+        metals = d["metals"]
+        par = dict(Vd=d["Vd"], high_G=1e5 * d["high_G"], low_G=d["low_G"], loop_G=1e7 * d["high_G"], tol=Q * 0.01, m_e=0.85 * 9.11e-31,
+                   V0=1.6, nn_dist=d["nn_dist"])
+        n1, layers, xyz, element, charge = d["N_contact"], 10, d["xyz"], d["element"], ref5["charge"]
+        cb = 1.60217663e-19 * d["Vd"] * (0.5 - np.clip(xyz[:, 0] / 52.0, 0, 1))            # a smooth band edge: enough for a storage test
+        lattice, sigma, kk, nmet = d["lattice"], d["sigma"], d["k"], len(d["metals"])
+    N = len(element)
+    res = {}
+    for dense in (0, 1):
+        monkeypatch.setenv("KMCF_SUB_DENSE", str(dense))
+        comm = S.KMC_comm(N, N, N, N)
+        comm.connect()
+        buf = S.GPUBuffers(N, element, xyz[:, 0], xyz[:, 1], xyz[:, 2], 52, sigma, kk, lattice, metals)
+        buf.site_charge.copy_(torch.as_tensor(np.asarray(charge, np.int32)))
+        buf.site_CB_edge = torch.as_tensor(np.asarray(cb, np.float64), device="cuda")
+        na = int(np.isin(element, [0, 1], invert=True).sum())
+        comm.counts_T, comm.displs_T = comm.partition(na + 1, 1)
+        S.initialize_sparsity_T(buf, 0, par["nn_dist"], n1, n1, layers, comm)
+        prm = S.current_params(par["Vd"], par["high_G"], par["low_G"], par["loop_G"], G0, par["tol"], par["m_e"], par["V0"], **kw)
+        S.t_assemble(buf, prm)
+        tn, v = S.t_tunnel(buf), S.t_vectors(buf)
+        n = S.t_info(buf)["Nsub"]
+        mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal(n)
+        p = torch.as_tensor(x, device="cuda")
+        Ap = torch.empty_like(p)
+        mat.spmv(p, Ap)
+        args = (n1, n1, layers, par["Vd"], par["high_G"], par["low_G"], par["loop_G"], G0, par["tol"], par["nn_dist"], par["m_e"], par["V0"], nmet)
+        buf.atom_virtual_potentials.zero_()
+        buf.site_power.zero_()
+        im, st = S.update_power_gpu_sparse_dist(buf, *args, True, False, 1.0, cg_tolerance=1e-13, cg_max_iterations=20000, **kw)
+        res[dense] = dict(tn=tn, dinv=v["dinv"], Ap=Ap.cpu().numpy(), x=x, im=im, st=st, m=buf.atom_virtual_potentials.cpu().numpy().copy(),
+                          pw=buf.site_power.cpu().numpy().copy(), n=n)
+        buf.freeGPUmemory()
+        comm.close()
+    a, b = res[0], res[1]
+    np.testing.assert_array_equal(a["tn"]["row_ptr"], b["tn"]["row_ptr"])
+    np.testing.assert_array_equal(a["tn"]["col"], b["tn"]["col"])
+    rows_of = np.repeat(np.arange(len(a["tn"]["row_ptr"]) - 1) + a["tn"]["first"], np.diff(a["tn"]["row_ptr"]))
+    off = a["tn"]["col"] != rows_of
+    np.testing.assert_array_equal(a["tn"]["val"][off], b["tn"]["val"][off])                                      # the same WKB values, bit for bit
+    np.testing.assert_allclose(b["tn"]["val"][~off], a["tn"]["val"][~off], rtol=1e-12)                           # diagonal entries = -(row sums)
+    np.testing.assert_allclose(b["tn"]["diag"], a["tn"]["diag"], rtol=1e-12)                                     # -(row sums): another order
+    np.testing.assert_allclose(b["dinv"], a["dinv"], rtol=1e-12)
+    # operator: |dy| <= 1e-12 * sum |a_ij x_j| with the sum bounded through the diagonal magnitudes
+    scale = np.abs(1.0 / a["dinv"]) * np.abs(a["x"]).max() * 2
+    assert np.all(np.abs(a["Ap"] - b["Ap"]) <= 1e-12 * scale), float((np.abs(a["Ap"] - b["Ap"]) / scale).max())
+    assert a["st"]["converged"] == b["st"]["converged"] == 1
+    assert abs(a["st"]["iterations"] - b["st"]["iterations"]) <= max(3, 0.1 * a["st"]["iterations"])
+    metal = np.r_[0, 1]
+    assert np.abs(a["m"][metal] - b["m"][metal]).max() <= 1e-6 * np.abs(a["m"]).max()
+    assert np.abs(a["pw"] - b["pw"]).max() <= 1e-5 * np.abs(a["pw"]).max() + 1e-300
+    np.testing.assert_array_equal(a["pw"] == 0, b["pw"] == 0)

@@ -250,6 +250,12 @@ def test_5nm_device(km, oracle, dev5, ref5, torch):
     res_o = np.linalg.norm(T.rhs - T.spmv(xo)) / np.linalg.norm(T.rhs)
     print("T 5 nm: true residual %.3e (oracle, natural order: %.3e)" % (res, res_o))
     assert res <= 3 * res_o, (res, res_o)
+    # the current from the loop side (Kirchhoff at the source node): equal to the reference's injection-side sum up to
+    # that node's residual, G0 |r_1| <= G0 sqrt(T_11 r.z) -- here small against the current itself
+    mm = buf.atom_virtual_potentials.cpu().numpy()
+    i_loop = loop_G * (d["Vd"] * G0 - (mm[1] - mm[0]))
+    assert abs(im - i_loop) <= G0 * np.sqrt((loop_G + NL * high_G) * st["rz"]) * 1.01, (im, i_loop)
+    print("T 5 nm: I_macro %.6e (injection side), %.6e (loop side)" % (im, i_loop))
     assert im > 0
     buf.freeGPUmemory()
     comm.close()

@@ -255,6 +255,31 @@ def test_full_size_current_and_heat(full, km):
     print("T 40 nm, tolerance 1e-21 N: %d iterations, %.1f ms, I_macro %.4e (injection side, the reference's), %.4e (loop side)"
           % (st_t["iterations"], st_t["ms_solve"], im_t, i_loop_t))
     assert st_t["converged"] == 1 and im_t > 0 and abs(im_t - i_loop_t) <= 0.01 * im_t, (im_t, i_loop_t)
+    if os.environ.get("KMCF_T_FULL_WINDOW"):
+        # once, not routinely: the reference's own tunnel-point set -- vacancies AND the contact Ti / N atoms inside its
+        # hard-coded window (get_is_tunnel_mpi, src/initialize_sparsity_T.cu:618-654, window at :645) -- at full size, in the
+        # reference's benchmark setting (100 iterations, current_solver_gpu.cu:1455-1456)
+        import time
+        prm_w = S.current_params(d["Vd"], high_G, low_G, loop_G, G0, Q * 0.01, 0.85 * 9.11e-31, 1.6)       # the default window = the reference's
+        t.cuda.synchronize()
+        free0 = t.cuda.mem_get_info()[0]
+        t0 = time.time()
+        S.t_assemble(buf, prm_w)
+        t.cuda.synchronize()
+        t_asm = time.time() - t0
+        iw = S.t_info(buf)
+        buf.atom_virtual_potentials.zero_()
+        im_w, st_w = S.update_power_gpu_sparse_dist(buf, NL, NL, 10, d["Vd"], high_G, low_G, loop_G, G0, Q * 0.01, d["nn_dist"],
+                                                    0.85 * 9.11e-31, 1.6, len(d["metals"]), True, True, 1.0)
+        free1 = t.cuda.mem_get_info()[0]
+        print("T 40 nm, reference window: %d tunnel points, %d entries (%.0f %% dense, %.2f GB of values), first assembly %.3f s (with allocation), "
+              "%d iterations, assembly %.1f ms, solve %.1f ms (%.2f ms per iteration), device memory %.1f GB more than before"
+              % (iw["tunnel_points"], iw["nnz_tunnel"], 100.0 * iw["nnz_tunnel"] / iw["tunnel_points"] ** 2, iw["nnz_tunnel"] * 8e-9, t_asm,
+                 st_w["iterations"], st_w["ms_assembly"], st_w["ms_solve"], st_w["ms_solve"] / max(st_w["iterations"], 1), (free0 - free1) / 1e9))
+        assert st_w["iterations"] == 100 and np.isfinite(im_w)
+        pw_w = buf.site_power.cpu().numpy()
+        assert np.all(pw_w[metal | ~atom] == 0) and np.all(pw_w >= 0) and pw_w.max() > 0
+        pw = pw_w                              # (site_power now holds this run's power: the heat check below uses it)
     # heat: Sum site_power -> T_bg (update_temperatureglobal_gpu) against the closed form on the same power
     a_c, b_c, nsteps, C_th, small = 0.9, 30.0, 25.0, 1e-12, 1e-9
     buf.T_bg.fill_(300.0)

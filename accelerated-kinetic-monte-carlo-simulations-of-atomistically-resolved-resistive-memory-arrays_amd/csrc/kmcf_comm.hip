@@ -121,6 +121,8 @@ extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int ran
     KMCF_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     KMCF_HIP(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     KMCF_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    KMCF_HIP(hipEventCreateWithFlags(&c->ev_subpack, hipEventDisableTiming));
+    KMCF_HIP(hipEventCreateWithFlags(&c->ev_sub, hipEventDisableTiming));
     KMCF_HIP(hipEventCreate(&c->ev_t0));
     KMCF_HIP(hipEventCreate(&c->ev_t1));
     KMCF_HIP(hipEventCreate(&c->ev_a0));
@@ -253,6 +255,8 @@ extern "C" int kmcf_comm_destroy(kmcf_comm *c)
     if (c->nccl_red) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_red));
     if (c->ev_packed) hipEventDestroy(c->ev_packed);
     if (c->ev_halo) hipEventDestroy(c->ev_halo);
+    if (c->ev_subpack) hipEventDestroy(c->ev_subpack);
+    if (c->ev_sub) hipEventDestroy(c->ev_sub);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
     if (c->ev_a0) hipEventDestroy(c->ev_a0);
@@ -545,6 +549,20 @@ static int allgatherv_impl(kmcf_comm *c, T *d_buf, const int *counts, const int 
 int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs)
 {
     return allgatherv_impl<double>(c, d_buf, counts, displs, ncclDouble);
+}
+
+int kmcf_comm_allgatherv_double_comm_stream(kmcf_comm *c, double *d_buf, const int *counts, const int *displs)
+{
+    if (c->p2p_active && c->nranks > 1 && kmcf_p2p_fits(c, ((size_t)displs[c->nranks - 1] + counts[c->nranks - 1]) * sizeof(double)))
+        return kmcf_p2p_allgatherv(c, d_buf, counts, displs, sizeof(double), c->comm_stream);
+    if (c->group || !c->nccl || c->nranks == 1) return KMCF_ERR_STATE;           // host-synchronous / nothing to overlap
+    ncclComm_t comm = static_cast<ncclComm_t>(c->nccl);                           // the comm stream's communicator (halos)
+    KMCF_NCCL(g_rccl.GroupStart());
+    for (int q = 0; q < c->nranks; ++q)
+        if (counts[q] > 0)
+            KMCF_NCCL(g_rccl.Broadcast(d_buf + displs[q], d_buf + displs[q], (size_t)counts[q], ncclDouble, q, comm, c->comm_stream));
+    KMCF_NCCL(g_rccl.GroupEnd());
+    return KMCF_OK;
 }
 
 int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs)

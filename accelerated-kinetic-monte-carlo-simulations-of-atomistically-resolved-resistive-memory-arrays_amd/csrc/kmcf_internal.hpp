@@ -96,6 +96,7 @@ struct kmcf_comm {
     hipStream_t comm_stream = nullptr;  // halo exchange stream
     hipEvent_t ev_packed = nullptr;     // compute -> comm
     hipEvent_t ev_halo = nullptr;       // comm -> compute
+    hipEvent_t ev_subpack = nullptr, ev_sub = nullptr;   // tunnel sub-vector: packed (compute -> comm), gathered (comm -> compute)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;   // assembly timing (kmcf_background_potential_sparse)
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;   // first / last device work of a kmcf_pcg_jacobi call
@@ -323,6 +324,7 @@ struct kmcf_subop {
     // as 64 x 64 tiles of f64 (zeros where the pattern has no entry), diagonal tiles complete.  Half the bytes of the
     // packed full block per application; every tile serves its block row (row sums) and, transposed out of LDS, its
     // block column (column sums); partial sums are written per strip / tile and added in a fixed order.
+    bool gather_pending = false;             // the sub-vector all-gather of the current SpMV runs on the comm stream
     bool dense = false;
     int nb = 0;                              // ceil(n_glob / 64)
     int n_strips = 0;
@@ -344,8 +346,12 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags
 // rows, sub-block), added in a fixed order by whoever consumes them
 struct kmcf_part4 { const double *p[4]; int n[4]; };
 kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m);
-// tstate.hip: y[sub rows] += S x_sub (+ dot partials) on the compute stream; x_sub gathered from m->d_p
-int kmcf_subop_apply(kmcf_matrix *m, bool with_dot, bool skip_if_done);
+// tstate.hip: y[sub rows] += S x_sub (+ dot partials).  begin: pack the local part of x_sub out of m->d_p and start the
+// all-gather of the ranks' parts -- on the comm stream where the transport allows, so that it runs underneath the
+// neighbour part of the SpMV (spmm_split_sparse2/3 post the exchange first and poll it, dist_spmv_split_sparse.cpp:
+// 123-192, 246-337); finish: wait for it, then the block's kernels on the compute stream
+int kmcf_subop_begin(kmcf_matrix *m, bool skip_if_done);
+int kmcf_subop_finish(kmcf_matrix *m, bool with_dot, bool skip_if_done);
 // Dictionary-code the values now in d_val (window kernel only; no-op otherwise).  h_dict/nd: the distinct
 // off-diagonal values; m->coded is set iff every off-diagonal value was found.  Synchronous.
 int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd);
@@ -370,6 +376,9 @@ int kmcf_comm_allreduce_sum(kmcf_comm *c, double *d_buf, int count);
 int kmcf_group_rendezvous(kmcf_comm *c);
 int kmcf_comm_send_recv_halo(kmcf_matrix *m);
 int kmcf_comm_allgatherv_double(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);
+// the same on the COMM stream (RCCL: the halo communicator), for gathers that overlap with work on the compute stream;
+// not for host-synchronous loopback groups (returns KMCF_ERR_STATE there: the caller keeps the in-order path)
+int kmcf_comm_allgatherv_double_comm_stream(kmcf_comm *c, double *d_buf, const int *counts, const int *displs);
 int kmcf_comm_allgatherv_int(kmcf_comm *c, int *d_buf, const int *counts, const int *displs);
 // p2p.hip
 int kmcf_p2p_create(kmcf_comm *c);
@@ -382,7 +391,7 @@ int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count);
 // finalize + all-reduce in ONE 1-block kernel: red[i] = sum over ranks of (sum of the partial arrays of part[i]);
 // returns at once (on every rank alike) when skip_if_done and S->done
 int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, kmcf_scalars *d_S, int skip_if_done);
-int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem);
+int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem, hipStream_t st = nullptr);
 int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8);
 int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8,
                             const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo);

@@ -369,8 +369,9 @@ int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, km
 }
 
 // In-place all-gather with uneven counts on the compute stream (elements of 4 or 8 bytes).
-int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem)
+int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem, hipStream_t st)
 {
+    if (!st) st = c->stream;
     kmcf_p2p *w = c->p2p;
     const int P = c->nranks, rank = c->rank;
     KMCF_CHECK(elem == 4 || elem == 8, KMCF_ERR_ARG, "p2p all-gather: element size %zu", elem);
@@ -393,10 +394,10 @@ int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
     const int g1 = (int)std::min<size_t>(std::max<size_t>(my_words / (KMCF_BLOCK * 4), 1), 48);
     const int g2 = (int)std::min<size_t>(std::max<size_t>(woff[P] / (KMCF_BLOCK * 4), 1), 48);
     unsigned int *buf32 = static_cast<unsigned int *>(d_buf);
-    p2p_gather_stage_kernel<<<g1, KMCF_BLOCK, 0, c->stream>>>(w->d_peer, P, rank, buf32 + woff[rank],
+    p2p_gather_stage_kernel<<<g1, KMCF_BLOCK, 0, st>>>(w->d_peer, P, rank, buf32 + woff[rank],
                                                               reinterpret_cast<unsigned int *>(w->win + half_off) + woff[rank], my_words,
                                                               w->seq_gather, w->timeout_ticks, w->d_err, w->h_err, w->d_ctr);
-    p2p_gather_pull_kernel<<<g2, KMCF_BLOCK, 0, c->stream>>>(w->d_peer, P, rank, half_off, wo, buf32, w->seq_gather, w->timeout_ticks,
+    p2p_gather_pull_kernel<<<g2, KMCF_BLOCK, 0, st>>>(w->d_peer, P, rank, half_off, wo, buf32, w->seq_gather, w->timeout_ticks,
                                                              w->d_err, w->h_err, w->d_ctr + 1);
     KMCF_HIP(hipGetLastError());
     return KMCF_OK;              // asynchronous like the RCCL path; a timeout shows in kmcf_p2p_check after the next sync

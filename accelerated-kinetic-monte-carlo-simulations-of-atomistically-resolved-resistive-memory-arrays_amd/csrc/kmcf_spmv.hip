@@ -1549,6 +1549,7 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags
         if (!(flags & 1)) KMCF_TRY(kmcf_p2p_direct_ack(m, seq, skip_if_done));
         return KMCF_OK;
     }
+    if (m->sub) KMCF_TRY(kmcf_subop_begin(m, skip_if_done));     // sub-vector: packed, its all-gather under way (comm stream)
     KMCF_TRY(kmcf_halo_exchange_begin(m));
     launch_interior(m, with_dot, skip_if_done);
     KMCF_HIP(hipGetLastError());
@@ -1573,7 +1574,7 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags
                                                                            m->d_Ap, m->d_long_part, m->d_long_ctr, part, m->d_S, chk);
         KMCF_HIP(hipGetLastError());
     }
-    if (m->sub) KMCF_TRY(kmcf_subop_apply(m, with_dot, skip_if_done));
+    if (m->sub) KMCF_TRY(kmcf_subop_finish(m, with_dot, skip_if_done));
     return KMCF_OK;
 }
 
@@ -1672,7 +1673,8 @@ extern "C" int kmcf_spmv_bench(kmcf_matrix *m, int reps, int with_dot, float *ms
 // (pack, send/recv, wait), 2 = the SpMV kernels alone (interior + boundary rows, no exchange).
 extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_total)
 {
-    KMCF_CHECK(m && reps > 0 && ms_total && kind >= 0 && kind <= 2, KMCF_ERR_ARG, "kmcf_comm_bench: bad argument");
+    KMCF_CHECK(m && reps > 0 && ms_total && kind >= 0 && kind <= 3, KMCF_ERR_ARG, "kmcf_comm_bench: bad argument");
+    KMCF_CHECK(kind != 3 || m->sub, KMCF_ERR_ARG, "kmcf_comm_bench: kind 3 (sub-vector all-gather) needs a split operator");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_comm_bench: host-only matrix");
     kmcf_comm *c = m->comm;
     KMCF_TRY(kmcf_enter(c));
@@ -1687,6 +1689,9 @@ extern "C" int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_tot
         } else if (kind == 1) {
             KMCF_TRY(kmcf_halo_exchange_begin(m));
             KMCF_TRY(kmcf_halo_exchange_end(m));
+        } else if (kind == 3) {                       // pack + all-gather of the tunnel sub-vector + the wait for it
+            KMCF_TRY(kmcf_subop_begin(m, false));
+            if (m->sub->gather_pending) { KMCF_HIP(hipStreamWaitEvent(c->stream, c->ev_sub, 0)); m->sub->gather_pending = false; }
         } else {
             launch_interior(m, true, false);
             if (m->n_halo > 0 && m->n_boundary_rows > 0) launch_vec_any(m, true, false, true);

@@ -1240,20 +1240,49 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
     return KMCF_OK;
 }
 
-// y[sub rows] += S x_sub on the compute stream (called by kmcf_spmv_device after the CSR part)
-int kmcf_subop_apply(kmcf_matrix *m, bool with_dot, bool skip_if_done)
+// Sub-block part of a split SpMV.  begin (called by kmcf_spmv_device BEFORE the CSR part): pack the local part of the
+// sub-vector (pack_gpu, dist_spmv_split_sparse.cpp:29-33) and start gathering the rest (:36-48) -- for a group on RCCL
+// or the peer-to-peer transport on the COMM stream, so that the exchange runs underneath the neighbour part
+// (spmm_split_sparse2 / 3, :123-192, :246-337); finish (after the CSR part): wait for it, y[sub rows] += S x_sub.
+int kmcf_subop_begin(kmcf_matrix *m, bool skip_if_done)
+{
+    kmcf_subop *sb = m->sub;
+    kmcf_comm *c = m->comm;
+    hipStream_t st = c->stream;
+    sb->gather_pending = false;
+    if (sb->n_glob == 0) return KMCF_OK;
+    const int chk = skip_if_done ? 1 : 0;
+    if (sb->n_loc > 0) {
+        sub_pack_kernel<<<grid1d(sb->n_loc), KMCF_BLOCK, 0, st>>>(sb->n_loc, sb->d_rows, m->d_p, sb->d_xsub + sb->row0, m->d_S, chk);
+        KMCF_HIP(hipGetLastError());
+    }
+    if (c->nranks == 1 && !c->force_collectives) return KMCF_OK;
+    static const bool no_overlap = getenv("KMCF_SUB_OVERLAP") && atoi(getenv("KMCF_SUB_OVERLAP")) == 0;
+    if (!no_overlap && (c->p2p_active || (!c->group && c->nccl))) {
+        KMCF_HIP(hipEventRecord(c->ev_subpack, st));
+        KMCF_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_subpack, 0));
+        const int rc = kmcf_comm_allgatherv_double_comm_stream(c, sb->d_xsub, sb->counts.data(), sb->displs.data());
+        if (rc == KMCF_OK) {
+            KMCF_HIP(hipEventRecord(c->ev_sub, c->comm_stream));
+            sb->gather_pending = true;
+            return KMCF_OK;
+        }
+        if (rc != KMCF_ERR_STATE) return rc;
+    }
+    return kmcf_comm_allgatherv_double(c, sb->d_xsub, sb->counts.data(), sb->displs.data());     // in order, on the compute stream
+}
+
+int kmcf_subop_finish(kmcf_matrix *m, bool with_dot, bool skip_if_done)
 {
     kmcf_subop *sb = m->sub;
     kmcf_comm *c = m->comm;
     hipStream_t st = c->stream;
     if (sb->n_glob == 0) return KMCF_OK;
     const int chk = skip_if_done ? 1 : 0;
-    // pack the local part of the sub-vector (pack_gpu, dist_spmv_split_sparse.cpp:29-33), gather the rest (:36-48)
-    if (sb->n_loc > 0) {
-        sub_pack_kernel<<<grid1d(sb->n_loc), KMCF_BLOCK, 0, st>>>(sb->n_loc, sb->d_rows, m->d_p, sb->d_xsub + sb->row0, m->d_S, chk);
-        KMCF_HIP(hipGetLastError());
+    if (sb->gather_pending) {
+        KMCF_HIP(hipStreamWaitEvent(st, c->ev_sub, 0));
+        sb->gather_pending = false;
     }
-    KMCF_TRY(kmcf_comm_allgatherv_double(c, sb->d_xsub, sb->counts.data(), sb->displs.data()));
     if (sb->n_loc == 0) return KMCF_OK;
     double *part = m->d_part_a + 3 * KMCF_MAX_PARTIALS;
     if (sb->dense) {

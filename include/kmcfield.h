@@ -200,7 +200,8 @@ int kmcf_spmv_replan(kmcf_matrix *m);
  * times `reps` repetitions of one piece of a distributed CG iteration on the
  * compute stream -- kind 0: the all-reduce of the 3 fused scalars, 1: the halo
  * exchange alone (pack, send/recv, wait), 2: the SpMV kernels alone (interior
- * + boundary rows, no exchange). */
+ * + boundary rows, no exchange), 3 (split operators only): pack + all-gather of
+ * the tunnel sub-vector + the wait for it. */
 int kmcf_comm_bench(kmcf_matrix *m, int kind, int reps, float *ms_total);
 
 typedef struct {

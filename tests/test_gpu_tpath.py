@@ -261,10 +261,19 @@ def test_5nm_device(km, oracle, dev5, ref5, torch):
     comm.close()
 
 
+@pytest.mark.parametrize("transport", ["loopback", "p2p"])
 @pytest.mark.parametrize("P", [2, 3])
-def test_small_device_multirank(km, oracle, torch, P):
-    """Row-partitioned T over a loopback group: halo exchange of the neighbour part, all-gather of the tunnel
-    sub-vector, replicated current and power."""
+def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):
+    """Row-partitioned T over an in-process group: halo exchange of the neighbour part, all-gather of the tunnel
+    sub-vector, replicated current and power.  transport "loopback": host-synchronous exchanges, in order; "p2p": the
+    device-side peer-to-peer protocol, where the sub-vector all-gather runs on the comm stream underneath the
+    neighbour part of every SpMV (kmcf_subop_begin / _finish).  Same results, bit for bit (the oracle's device-order run
+    does not know the transport)."""
+    if transport == "p2p":
+        monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+        monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
+    else:
+        monkeypatch.delenv("KMCF_TRANSPORT", raising=False)
     S = km.solvers
     d = small_device(seed=11)
     a = 2.5

@@ -38,6 +38,9 @@ struct kmcf_event_cache {
     double *d_u = nullptr, *d_totlog = nullptr;     // batch: uniforms in, totals out
     int *d_evlog = nullptr;
     void *d_state = nullptr;
+    // row-aligned sum tree of the persistent batch kernel: one sum per row (nn slots), per tile of EV_RT rows, per
+    // group of EV_GROUP tiles
+    double *d_rsum = nullptr, *d_tsum2 = nullptr, *d_gsum2 = nullptr;
     const int *sym_key = nullptr;       // neighbour list the symmetry verdict belongs to
     int sym_N = 0;
     bool symmetric = false;
@@ -52,7 +55,7 @@ void kmcf_event_cache_free(kmcf_comm *c)
     if (!c || !c->ev_cache) return;
     kmcf_event_cache *w = c->ev_cache;
     void *ptrs[] = {w->d_type, w->d_prob, w->d_tsum, w->d_gsum, w->d_tot, w->d_ij, w->d_aff, w->d_asym,
-                    w->d_u, w->d_totlog, w->d_evlog, w->d_state, w->d_neigh_full};
+                    w->d_u, w->d_totlog, w->d_evlog, w->d_state, w->d_neigh_full, w->d_rsum, w->d_tsum2, w->d_gsum2};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete w;
@@ -419,6 +422,230 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent batch kernel (one rank holding all rows, symmetric neighbour lists): ONE block of 16 wavefronts runs a
+// whole batch of events -- select, execute, zero what the event invalidates, refresh the sums -- with no launch and
+// no host round trip in between.  What makes one block enough is a sum tree aligned to ROWS: one sum per row of nn
+// slots, per tile of EV_RT rows, per group of EV_GROUP tiles.  An event empties the rows of i and j (their sums
+// become 0) and removes the slots that point to them from the rows of their <= 2 nn neighbours: a wavefront per such
+// row reads its nn neighbour ids and probabilities (two coalesced loads), zeroes, and adds the row up again on the
+// spot (44 KB per event at nn = 52; the slot-aligned tree of the three-launch path re-adds <= 4 nn + 4 tiles of 2048
+// slots, 1.6 MB, which took 212 blocks); then half a wavefront per touched tile adds its EV_RT row sums and a
+// wavefront per touched group its EV_GROUP tile sums.  Fixed orders (the step's build kernel uses the same
+// functions): row = butterfly over the nn lanes; tile = butterfly over 32 lanes; group = four consecutive tile sums
+// per lane, then the butterfly.
+constexpr int EV_RT = 32;
+constexpr int EV_PB = 1024;                                 // threads of the persistent block
+
+__device__ __forceinline__ double ev_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double ev_half_sum(double v)    // over the 32 lanes of a half wavefront
+{
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// sum of a group's tile sums (a whole wavefront)
+__device__ __forceinline__ double ev_group_sum(const double *__restrict__ tsum, long long g, long long n_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t0 = g * EV_GROUP + 4 * lane;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += t0 + k < n_tiles ? tsum[t0 + k] : 0.0;
+    return ev_wave_sum(s);
+}
+
+// level 0: row sums (a wavefront per row), 1: tile sums (half a wavefront per tile), 2: group sums (a wavefront per group)
+__global__ __launch_bounds__(KMCF_BLOCK) void ev_tree_level_kernel(int level, long long n_out, long long n_in, int nn,
+                                                                   const double *__restrict__ in, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * KMCF_BLOCK + threadIdx.x) >> 6, n_waves = (long long)gridDim.x * (KMCF_BLOCK / 64);
+    if (level == 0) {
+        for (long long r = wave; r < n_out; r += n_waves) {
+            const double v = ev_wave_sum(lane < nn ? in[r * nn + lane] : 0.0);
+            if (lane == 0) out[r] = v;
+        }
+    } else if (level == 1) {
+        for (long long tp = wave; 2 * tp < n_out; tp += n_waves) {
+            const long long tile = 2 * tp + (lane >> 5), row = tile * EV_RT + (lane & 31);
+            const double v = ev_half_sum(tile < n_out && row < n_in ? in[row] : 0.0);
+            if ((lane & 31) == 0 && tile < n_out) out[tile] = v;
+        }
+    } else {
+        for (long long g = wave; g < n_out; g += n_waves) {
+            const double v = ev_group_sum(in, g, n_in);
+            if (lane == 0) out[g] = v;
+        }
+    }
+}
+
+struct event_batch_args {
+    int count, nn, nbatch;
+    long long n_tiles, n_groups;
+    double inv_freq;
+};
+
+__global__ __launch_bounds__(EV_PB) void event_batch_kernel(
+    event_batch_args A, double *__restrict__ prob, unsigned char *__restrict__ type, const int *__restrict__ neigh,
+    double *__restrict__ rsum, double *__restrict__ tsum, double *__restrict__ gsum, int *__restrict__ site_element,
+    int *__restrict__ site_charge, int *__restrict__ evlog, double *__restrict__ totlog, const double *__restrict__ batch_u,
+    event_batch_state *__restrict__ state)
+{
+    __shared__ int s_ij[3];
+    __shared__ int s_stop;
+    __shared__ int s_rows[2 * 64 + 2];                     // rows whose events change: the neighbours of i and of j, i, j
+    __shared__ int s_uniq[2 * 64 + 2];                     // bit 0 / 1: first entry of its tile / group in s_rows
+    __shared__ int s_rmin;                                 // smallest touched row
+    __shared__ unsigned long long s_tmask[32], s_gmask;    // tiles / groups already claimed, relative to s_rmin's
+    const int nn = A.nn, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int NW = EV_PB / 64;
+    const int n_aff = 2 * nn + 2;
+#ifdef KMCF_EV_PROFILE
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
+#define EV_TICK(k) { const long long now_ = wall_clock64(); tk[k] += now_ - t_prev; t_prev = now_; }
+#else
+#define EV_TICK(k)
+#endif
+    for (int ev = 0; ev < A.nbatch; ++ev) {
+        // ---- select (first wavefront): groups -> tiles of the group -> rows of the tile -> slots of the row
+        if (t < 64) {
+            double sum = 0.0;
+            for (long long g = t; g < A.n_groups; g += 64) sum += gsum[g];
+            const double total = ev_wave_sum(sum);
+            const double number = batch_u[2 * ev] * total;
+            double acc = 0.0;
+            int g = wave_search<4>(gsum, (int)A.n_groups, number, &acc);
+            if (g < 0) g = 0;
+            const long long b0 = (long long)g * EV_GROUP;
+            int b = wave_search<4>(tsum + b0, (int)(b0 + EV_GROUP < A.n_tiles ? EV_GROUP : A.n_tiles - b0), number, &acc);
+            const long long tile = b0 + (b < 0 ? 0 : b);
+            const long long r0 = tile * EV_RT;
+            int r = wave_search<1>(rsum + r0, (int)(r0 + EV_RT < A.count ? EV_RT : A.count - r0), number, &acc);
+            const long long row = r0 + (r < 0 ? 0 : r);
+            int k = wave_search<1>(prob + row * nn, nn, number, &acc);
+            if (k < 0) k = 0;
+            const long long id = row * nn + k;
+            if (t == 0) {
+                const int i = (int)row, j = neigh[id], et = (int)type[id];
+                evlog[3 * ev] = s_ij[0] = i;
+                evlog[3 * ev + 1] = s_ij[1] = j;
+                evlog[3 * ev + 2] = s_ij[2] = et;
+                totlog[2 * ev] = total;
+                int stop = 0;
+                if (j < 0) {
+                    state->done = 2;                           // nothing selectable: the host reports it
+                    stop = 1;
+                } else {
+                    if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
+                    else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
+                    else if (et == EV_VDIFF || et == EV_ODIFF) {
+                        const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
+                        const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+                    }
+                    state->n_exec = ev + 1;
+                    const double t_res = -log(batch_u[2 * ev + 1]) / total;          // :479; the device decides whether the step goes on
+                    totlog[2 * ev + 1] = t_res;
+                    if (!(t_res < A.inv_freq)) { state->done = 1; stop = 1; }         // this event was the step's last
+                }
+                s_stop = stop;
+            }
+        }
+        __syncthreads();
+        EV_TICK(0)
+        if (s_stop) break;                                     // (the sums are rebuilt by the next step's build)
+        const int i_del = s_ij[0], j_del = s_ij[1];
+        // ---- rows of i and j lose all their events (zero_out_events_split, :237-256, through the symmetric lists)
+        if (t == EV_PB - 1) s_rmin = i_del < j_del ? i_del : j_del;
+        if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
+        __syncthreads();
+        if (t < 2 * nn) {
+            const int srow = t < nn ? i_del : j_del;
+            const long long own = (long long)srow * nn + (t < nn ? t : t - nn);
+            const int n = neigh[own];
+            s_rows[t] = n;
+            if (n >= 0) { type[own] = (unsigned char)EV_NULL; prob[own] = 0.0; atomicMin(&s_rmin, n); }
+        }
+        if (t == 0) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; }
+        __syncthreads();
+        EV_TICK(1)
+        // ---- a wavefront per neighbour row: drop the slots that point to i or j, add the row up again (four rows per
+        // wavefront and step: their loads are in flight together)
+        for (int e0 = wv; e0 < 2 * nn; e0 += 4 * NW) {
+            int n[4], jj[4];
+            double pv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * NW;
+                n[q] = e < 2 * nn ? s_rows[e] : -1;
+                const long long sl = (long long)(n[q] >= 0 ? n[q] : 0) * nn + (lane < nn ? lane : 0);
+                jj[q] = neigh[sl];
+                pv[q] = prob[sl];
+            }
+#ifdef KMCF_EV_PROFILE
+            asm volatile("" ::"v"(jj[0]), "v"(jj[1]), "v"(jj[2]), "v"(jj[3]), "v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(pv[3]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            EV_TICK(5)
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long sl = (long long)(n[q] >= 0 ? n[q] : 0) * nn + lane;
+                const bool mine = n[q] >= 0 && lane < nn;
+                double v = mine ? pv[q] : 0.0;
+                if (mine && (jj[q] == i_del || jj[q] == j_del)) { type[sl] = (unsigned char)EV_NULL; prob[sl] = 0.0; v = 0.0; }
+                v = ev_wave_sum(v);
+                if (lane == 0 && n[q] >= 0) rsum[n[q]] = v;
+            }
+            EV_TICK(6)
+        }
+        // which entries are the first of their tile / group (the others would only repeat the same sums): a bit per tile /
+        // group relative to the smallest touched row's; whoever sets it first owns it (a tile / group out of the
+        // masks' range is simply added again by every entry that touches it)
+        if (t < n_aff) {
+            const int row = s_rows[t];
+            int u = 0;
+            if (row >= 0) {
+                const int trel = row / EV_RT - s_rmin / EV_RT, grel = row / (EV_RT * EV_GROUP) - s_rmin / (EV_RT * EV_GROUP);
+                u = 3;
+                if (trel < 2048 && (atomicOr(&s_tmask[trel >> 6], 1ull << (trel & 63)) >> (trel & 63)) & 1ull) u &= ~1;
+                if (grel < 64 && (atomicOr(&s_gmask, 1ull << grel) >> grel) & 1ull) u &= ~2;
+            }
+            s_uniq[t] = u;
+        }
+        __syncthreads();
+        EV_TICK(2)
+        // ---- tile sums: half a wavefront per touched tile
+        for (int e = 2 * wv + (lane >> 5); e < n_aff; e += 2 * NW) {
+            const int row = s_rows[e];
+            const bool on = row >= 0 && (s_uniq[e] & 1);
+            const long long tile = on ? row / EV_RT : 0, rr = tile * EV_RT + (lane & 31);
+            const double v = ev_half_sum(on && rr < A.count ? rsum[rr] : 0.0);
+            if (on && (lane & 31) == 0) tsum[tile] = v;
+        }
+        __syncthreads();
+        EV_TICK(3)
+        // ---- group sums: a wavefront per touched group
+        for (int e = wv; e < n_aff; e += NW) {
+            const int row = s_rows[e];
+            if (row < 0 || !(s_uniq[e] & 2)) continue;        // wavefront-uniform
+            const long long g = (row / EV_RT) / EV_GROUP;
+            const double v = ev_group_sum(tsum, g, A.n_tiles);
+            if (lane == 0) gsum[g] = v;
+        }
+        __syncthreads();
+        EV_TICK(4)
+    }
+#ifdef KMCF_EV_PROFILE
+    if (t == 0) printf("event batch of %d: ticks select %lld zero-own %lld nbr-rows(rest) %lld tiles %lld groups %lld | nbr loads %lld nbr process %lld\n", A.nbatch, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
+#endif
+}
+
 // execute_event, :284-331
 __global__ void execute_event_kernel(int *__restrict__ site_element, int *__restrict__ site_charge, const int *__restrict__ ijevent)
 {
@@ -568,13 +795,29 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         // its state and the real generator is advanced by what was consumed, so the caller's stream is used
         // exactly as by the reference (two draws per executed event); a foreign callback cannot be rewound,
         // so it gets batches of one.
-        group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
-        constexpr int BMAX = 128;
+        // persistent batch kernel (default; KMCF_EVENTS_PERSISTENT=0: three launches per event) with its row-aligned sums
+        const bool persistent = !(getenv("KMCF_EVENTS_PERSISTENT") && atoi(getenv("KMCF_EVENTS_PERSISTENT")) == 0) && nn <= 64;
+        const long long n_tiles2 = ((long long)count + EV_RT - 1) / EV_RT, n_groups2 = (n_tiles2 + EV_GROUP - 1) / EV_GROUP;
+        if (persistent) {
+            if (!w->d_rsum &&
+                (hipMalloc(reinterpret_cast<void **>(&w->d_rsum), (size_t)std::max(count, 1) * sizeof(double)) != hipSuccess ||
+                 hipMalloc(reinterpret_cast<void **>(&w->d_tsum2), (size_t)std::max<long long>(n_tiles2, 1) * sizeof(double)) != hipSuccess ||
+                 hipMalloc(reinterpret_cast<void **>(&w->d_gsum2), (size_t)std::max<long long>(n_groups2, 1) * sizeof(double)) != hipSuccess)) fail(KMCF_ERR_HIP);
+            if (rc == KMCF_OK) {
+                auto lgrid = [](long long n_waves) { return (int)std::min<long long>(std::max<long long>((n_waves + 3) / 4, 1), 65536); };
+                ev_tree_level_kernel<<<lgrid(count), KMCF_BLOCK, 0, st>>>(0, count, (long long)M, nn, d_prob, w->d_rsum);
+                ev_tree_level_kernel<<<lgrid((n_tiles2 + 1) / 2), KMCF_BLOCK, 0, st>>>(1, n_tiles2, count, nn, w->d_rsum, w->d_tsum2);
+                ev_tree_level_kernel<<<lgrid(n_groups2), KMCF_BLOCK, 0, st>>>(2, n_groups2, n_tiles2, nn, w->d_tsum2, w->d_gsum2);
+            }
+        } else {
+            group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
+        }
+        const int BMAX = persistent ? 512 : 128;
         const bool own_rng = (next_random == kmcf_rng_next);
         if (!w->d_u &&
-            (hipMalloc(reinterpret_cast<void **>(&w->d_u), 2 * BMAX * sizeof(double)) != hipSuccess ||
-             hipMalloc(reinterpret_cast<void **>(&w->d_totlog), 2 * BMAX * sizeof(double)) != hipSuccess ||
-             hipMalloc(reinterpret_cast<void **>(&w->d_evlog), 3 * BMAX * sizeof(int)) != hipSuccess ||
+            (hipMalloc(reinterpret_cast<void **>(&w->d_u), 2 * 512 * sizeof(double)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_totlog), 2 * 512 * sizeof(double)) != hipSuccess ||
+             hipMalloc(reinterpret_cast<void **>(&w->d_evlog), 3 * 512 * sizeof(int)) != hipSuccess ||
              hipMalloc(reinterpret_cast<void **>(&w->d_state), sizeof(event_batch_state)) != hipSuccess)) fail(KMCF_ERR_HIP);
         double *d_u = w->d_u, *d_totlog = w->d_totlog;
         int *d_evlog = w->d_evlog;
@@ -594,7 +837,13 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
             event_batch_state hs = {0, 0};
             if (hipMemcpyAsync(d_u, h_u.data(), 2 * nbatch * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
-            for (int ev = 0; ev < nbatch; ++ev) {
+            if (persistent) {
+                event_batch_args A;
+                A.count = count; A.nn = nn; A.nbatch = nbatch; A.n_tiles = n_tiles2; A.n_groups = n_groups2; A.inv_freq = 1 / freq;
+                event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
+                                                            d_site_charge, d_evlog, d_totlog, d_u, d_state);
+            }
+            for (int ev = 0; ev < nbatch && !persistent; ++ev) {
                 select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, 0.0, d_gsum, d_tsum, d_prob, d_type,
                                                                     d_neigh_idx, d_evlog, d_totlog, d_site_element, d_site_charge,
                                                                     d_aff, ev, d_u, d_state, 1 / freq);

@@ -513,6 +513,8 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
 #else
 #define EV_TICK(k)
 #endif
+    if (t == EV_PB - 1) s_rmin = INT_MAX;
+    if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
     for (int ev = 0; ev < A.nbatch; ++ev) {
         // ---- select (first wavefront): groups -> tiles of the group -> rows of the tile -> slots of the row
         if (t < 64) {
@@ -562,9 +564,6 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         if (s_stop) break;                                     // (the sums are rebuilt by the next step's build)
         const int i_del = s_ij[0], j_del = s_ij[1];
         // ---- rows of i and j lose all their events (zero_out_events_split, :237-256, through the symmetric lists)
-        if (t == EV_PB - 1) s_rmin = i_del < j_del ? i_del : j_del;
-        if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
-        __syncthreads();
         if (t < 2 * nn) {
             const int srow = t < nn ? i_del : j_del;
             const long long own = (long long)srow * nn + (t < nn ? t : t - nn);
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             s_rows[t] = n;
             if (n >= 0) { type[own] = (unsigned char)EV_NULL; prob[own] = 0.0; atomicMin(&s_rmin, n); }
         }
-        if (t == 0) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; }
+        if (t == 0) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; atomicMin(&s_rmin, i_del < j_del ? i_del : j_del); }
         __syncthreads();
         EV_TICK(1)
         // ---- a wavefront per neighbour row: drop the slots that point to i or j, add the row up again (four rows per
@@ -638,6 +637,8 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             const double v = ev_group_sum(tsum, g, A.n_tiles);
             if (lane == 0) gsum[g] = v;
         }
+        if (t == EV_PB - 1) s_rmin = INT_MAX;                  // (for the next event; nobody reads them in this phase)
+        if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
         __syncthreads();
         EV_TICK(4)
     }

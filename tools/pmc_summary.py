@@ -26,6 +26,7 @@ def load(d):
 def main():
     fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
     n_rows = int(sys.argv[4]) if len(sys.argv) > 4 else 1597080
+    workload = sys.argv[5] if len(sys.argv) > 5 else None
     vec = n_rows * 8.0
     rows = []
     for k in sorted(fetch):
@@ -37,22 +38,24 @@ def main():
             f.write("%s,%d,%.1f,%.1f\n" % r)
     def get(name):
         return [r for r in rows if r[0].startswith(name)]
-    p = get("cg_p_kernel")[0]
-    xr = get("cg_xr_kernel")[0]
-    cal_p = p[2] * 1024 / (4 * vec)
-    cal_xr = xr[2] * 1024 / (3 * vec)
-    cal_w = xr[3] * 1024 / (1 * vec)
+    cal = {}
+    if get("cg_p_kernel") and get("cg_xr_kernel"):          # (absent from runs that only launch the SpMV)
+        p = get("cg_p_kernel")[0]
+        xr = get("cg_xr_kernel")[0]
+        cal = dict(cg_p_fetch_ratio=round(p[2] * 1024 / (4 * vec), 4), cg_xr_fetch_ratio=round(xr[2] * 1024 / (3 * vec), 4),
+                   cg_xr_write_ratio=round(xr[3] * 1024 / (1 * vec), 4))
     # every SpMV kernel of the run (the bench line times the plan's kernel and, re-planned, the CSR stream kernel)
     kernels = []
     for sp in get("spmv_"):
         if sp[1] < 3:
             continue
         corrected = 2.0 * sp[2] * 1024 + sp[3] * 1024
-        kernels.append(dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
-                            corrected_bytes_per_launch=int(corrected), rows=n_rows))
-    res = dict(kernels=kernels,
-               calibration=dict(cg_p_fetch_ratio=round(cal_p, 4), cg_xr_fetch_ratio=round(cal_xr, 4),
-                                cg_xr_write_ratio=round(cal_w, 4)))
+        e = dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
+                 corrected_bytes_per_launch=int(corrected), rows=n_rows)
+        if workload:
+            e["workload"] = workload
+        kernels.append(e)
+    res = dict(kernels=kernels, calibration=cal)
     json.dump(res, open(out + ".json", "w"), indent=1)
     print(json.dumps(res))
 

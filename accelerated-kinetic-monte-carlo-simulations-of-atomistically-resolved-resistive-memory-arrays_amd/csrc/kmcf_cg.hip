@@ -330,7 +330,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     part_ref pbb = multi ? pr1(&S->red[1], 1) : pbb_loc;
     part_ref ppap = multi ? pr1(&S->red[2], 1) : ppap_loc;
 
-    KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
+    if (!(flags & 1) || n == 0) KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));      // (flag 1: the input kernel zeroed them)
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
     // p <- x0 ; Ap = A x0 ; r = b - Ap ; z ; r.z ; b.b    (:178-213)
     if (!(flags & 1)) KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -390,9 +390,11 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
     // the loop condition is evaluated once more after the last iteration (:217): it
     // decides `converged` and provides the printed residual (:273)
     if (!done) {
-        cg_tail_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz, S);
-        KMCF_HIP(hipGetLastError());
-        if (!(flags & 2)) {                        // (with flag 2 the caller's output kernel applies it on its way)
+        if (!(flags & 2) || multi) {               // (with flag 2 the caller's output kernel forms this last r.z itself ...
+            cg_tail_kernel<<<1, KMCF_BLOCK, 0, st>>>(prz, S);
+            KMCF_HIP(hipGetLastError());
+        }
+        if (!(flags & 2)) {                        //  ... and applies the pending x update on its way)
             cg_x_kernel<<<vg, KMCF_BLOCK, 0, st>>>(n, m->d_x, m->d_p, S);
             KMCF_HIP(hipGetLastError());
         }
@@ -653,7 +655,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
     part_ref pd = multi ? pr1(&S->red[1], 1) : pd_loc;
     part_ref pb = multi ? pr1(&S->red[2], 1) : pb_loc;
 
-    KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));
+    if (!(flags & 1) || n == 0) KMCF_HIP(hipMemsetAsync(S, 0, sizeof(kmcf_scalars), st));      // (flag 1: the input kernel zeroed them)
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
     if (!(flags & 1)) KMCF_HIP(hipMemcpyAsync(m->d_p, m->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     KMCF_TRY(kmcf_spmv_device(m, false, false));                       // A x0
@@ -884,8 +886,10 @@ __device__ __forceinline__ void xcd_range(int n, int &first, int &end, int &stri
 __global__ __launch_bounds__(KMCF_BLOCK) void cg_in_kernel(int n, const int *__restrict__ perm, const double *__restrict__ r_u,
                                                            const double *__restrict__ x_u, const double *__restrict__ dinv_u,
                                                            double *__restrict__ r, double *__restrict__ x, double *__restrict__ p,
-                                                           double *__restrict__ dinv)
+                                                           double *__restrict__ dinv, kmcf_scalars *__restrict__ S)
 {
+    // the solve's scalars start at zero (a memset of its own between this kernel and the first SpMV cost ~10 us of stream time)
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(kmcf_scalars) / sizeof(int)) reinterpret_cast<int *>(S)[threadIdx.x] = 0;
     int first, end, stride;
     xcd_range(n, first, end, stride);
     for (int i = first; i < end; i += stride) {
@@ -900,10 +904,22 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_in_kernel(int n, const int *__r
 __global__ __launch_bounds__(KMCF_BLOCK) void cg_out_kernel(int n, const int *__restrict__ perm, const double *__restrict__ r,
                                                             const double *__restrict__ x, const double *__restrict__ p,
                                                             double *__restrict__ r_u, double *__restrict__ x_u,
-                                                            const kmcf_scalars *__restrict__ S, kmcf_scalars *__restrict__ host_S)
+                                                            const kmcf_scalars *__restrict__ S, kmcf_scalars *__restrict__ host_S,
+                                                            part_ref tail_rz)
 {
-    // the solve's scalars straight into pinned host memory: a 120-byte hipMemcpyAsync costs tens of microseconds
-    if (host_S && blockIdx.x == 0 && threadIdx.x == 0) *host_S = *S;
+    __shared__ double lds4[4];
+    // the solve's scalars straight into pinned host memory: a 120-byte hipMemcpyAsync costs tens of microseconds.
+    // tail_rz (classic loop of one rank that ended on its iteration limit): the loop condition's last r.z (:217, :273) is
+    // the sum of these partials -- formed here by block 0 exactly as cg_tail_kernel forms it, instead of in a launch of its own
+    if (host_S && blockIdx.x == 0) {
+        const bool tail = tail_rz.n[0] > 0 && !S->done;
+        const double t = tail ? reduce_partials(tail_rz, lds4) : 0.0;       // (block-uniform branch)
+        if (threadIdx.x == 0) {
+            kmcf_scalars h = *S;
+            if (tail) h.rz_last = t;
+            *host_S = h;
+        }
+    }
     // a loop that ended on its iteration limit has left its last x += alpha p to this kernel (cg_p_kernel)
     const bool pending = !S->done && S->x_pending;
     const double a = S->xa;
@@ -942,12 +958,14 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     const double t_a = trace ? now() : 0.0;
     KMCF_HIP(hipEventRecord(c->ev_call0, c->stream));
     if (n > 0) {
-        cg_in_kernel<<<perm_grid(n), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, d_r, d_x, d_diag_inv, m->d_r, m->d_x, m->d_p, m->d_dinv);
+        cg_in_kernel<<<perm_grid(n), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, d_r, d_x, d_diag_inv, m->d_r, m->d_x, m->d_p, m->d_dinv, m->d_S);
         KMCF_HIP(hipGetLastError());
     }
     KMCF_TRY(pcg_workspace_flags(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats, 1 | 2));
     const double t_b = trace ? now() : 0.0;
-    cg_out_kernel<<<perm_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, m->d_p, d_r, d_x, m->d_S, c->h_scal);
+    const bool tail_here = !(c->nranks > 1 || c->force_collectives) && !kmcf_cg_single_reduction(m) && n > 0;
+    cg_out_kernel<<<perm_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, m->d_p, d_r, d_x, m->d_S, c->h_scal,
+                                                                           tail_here ? pr1(m->d_part_b, vec_grid(n)) : pr_none());
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipEventRecord(c->ev_call1, c->stream));
     // results visible on return (:271 hipDeviceSynchronize)

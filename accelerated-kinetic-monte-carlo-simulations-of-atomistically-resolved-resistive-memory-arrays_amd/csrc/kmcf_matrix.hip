@@ -345,8 +345,10 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
         for (int a = 0; a < P; ++a)
             for (int b = 0; b < P; ++b)
                 KMCF_CHECK(tab[(size_t)W * a + b] == tab[(size_t)W * b + P + a], KMCF_ERR_COMM,
-                           "kmcf_matrix_build: rank %d sends %d halo values to rank %d, which expects %d (matrix not structurally symmetric?)",
-                           a, tab[(size_t)W * a + b], b, tab[(size_t)W * b + P + a]);
+                           "kmcf_matrix_build: rank %d sends %d halo values to rank %d, which expects %d (matrix not structurally symmetric?)"
+                           " [seen by rank %d; its own rows: sends %d / expects %d; halo sizes in the table: %d, %d]",
+                           a, tab[(size_t)W * a + b], b, tab[(size_t)W * b + P + a], rank, (int)m->rows_per_neighbour.size(),
+                           (int)m->cols_per_neighbour.size(), tab[(size_t)W * a + 5 * P + b], tab[(size_t)W * b + 5 * P + a]);
         if (c->p2p_active) {
             std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0), r_ack((size_t)nnb, 0), r_halo((size_t)nnb, 0);
             for (int k = 1; k < nnb; ++k) {

@@ -258,6 +258,8 @@ int kmcf_p2p_create(kmcf_comm *c)
         (void)hipGetLastError();
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&w->win), w->win_bytes));
     }
+    if (getenv("KMCF_P2P_VERBOSE")) fprintf(stderr, "kmcfield p2p: rank %d window %zu MB at %p, %s\n", c->rank, w->win_bytes >> 20, (void *)w->win,
+                                            w->fine_grained ? "fine-grained" : "COARSE-grained (hipExtMallocWithFlags refused)");
     KMCF_HIP(hipMemset(w->win, 0, P2P_OFF_BUMP));
     w->stage_half = align_up((w->win_bytes - P2P_OFF_BUMP) / 4, 4096);       // half of the window for the two staging halves
     w->stage_off = P2P_OFF_BUMP;

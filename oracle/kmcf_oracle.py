@@ -274,7 +274,8 @@ class _DevPlan(C.Structure):
                 ("vec_grid", C.c_int), ("sell_grid", C.c_int), ("n_tiles", C.c_int), ("tile_first", _ipt), ("tile_rows", _ipt),
                 ("boundary_grid", C.c_int), ("boundary_lpr", C.c_int), ("n_boundary", C.c_int), ("boundary_rows", _ipt),
                 ("n_long_items", C.c_int), ("long_items", _ipt), ("sub_grid", C.c_int), ("sub_n", C.c_int), ("sub_rows", _ipt),
-                ("sub_rp", _ipt), ("sub_col", _ipt), ("sub_val", _dpt)]
+                ("sub_rp", _ipt), ("sub_col", _ipt), ("sub_val", _dpt), ("sub_dense", C.c_int), ("sub_n_glob", C.c_int),
+                ("sub_strip", C.c_int), ("sub_full", _dpt)]
 
 
 class DeviceRank:
@@ -315,11 +316,20 @@ class DeviceRank:
             self.sub_rows = self.sub_rp = self.sub_col = np.zeros(1, np.int32)
             self.sub_val = np.zeros(1)
             sub_n = sub_grid = 0
+        # dense symmetric storage of the block (one rank): the full block as a dense array for the tile walk
+        self.sub_full = np.zeros(1)
+        dense = int(bool(sub is not None and sub.get("dense")))
+        if dense:
+            nt = len(self.sub_rows)
+            full = np.zeros((nt, nt))
+            rows_of = np.repeat(np.arange(nt), np.diff(self.sub_rp))
+            full[rows_of, self.sub_col] = self.sub_val
+            self.sub_full = np.ascontiguousarray(full).reshape(-1)
         self.c = _DevPlan(self.n, self.n_short, self.n_halo, pi(self.rp), pi(self.col), pd(self.val), int(plan["vec_grid"]),
                           int(plan["sell_grid"]), len(self.tile_first), pi(self.tile_first), pi(self.tile_rows),
                           int(plan["boundary_grid"]), int(plan["boundary_lpr"]), len(self.boundary), pi(self.boundary),
                           len(items), pi(self.long_items), sub_grid, sub_n, pi(self.sub_rows), pi(self.sub_rp), pi(self.sub_col),
-                          pd(self.sub_val))
+                          pd(self.sub_val), dense, sub_n if dense else 0, int(sub.get("strip", 16)) if dense else 16, pd(self.sub_full))
         assert len(self.boundary) == int(plan["boundary_rows"]) or self.n_halo == 0
         assert len(items) == int(plan["long_items"])
 

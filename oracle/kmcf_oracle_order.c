@@ -347,6 +347,9 @@ typedef struct {
     const int *sub_rows;                          /* internal row of every local sub row                             */
     const int *sub_rp, *sub_col;                  /* its CSR over the gathered sub-vector (ascending columns)        */
     const double *sub_val;
+    int sub_dense;                                /* 1: the block is applied from dense symmetric 64 x 64 tiles       */
+    int sub_n_glob, sub_strip;                    /* points of all ranks (= this rank's: one rank only); tiles per strip */
+    const double *sub_full;                       /* sub_n_glob x sub_n_glob, row-major, zeros where there is no entry */
 } orc_dev_plan;
 
 /* One distributed SpMV of one rank, y = A x with x = [own | halo] (+ S x_sub on the sub rows), every row and every
@@ -445,6 +448,53 @@ void orc_dev_spmv(const orc_dev_plan *pl, const double *x, const double *xsub, d
         pc[0] = block_sum(dot);
         free(lpart);
     }
+    /* ---- sub-block, dense symmetric storage: sub_symm_kernel + sub_symm_reduce_kernel (csrc/kmcf_tstate.hip).  Upper
+     * tiles (I, J >= I) in strips of sub_strip tiles of one block row: lane r adds row r's products column by column and
+     * runs on through the strip's tiles; lane c adds column c's products row by row (not for diagonal tiles).  Block row
+     * B: wave w adds the column parts of tiles (K, B), K = w, w + 4, ... < B and the strips first + w, + 4, ...; joined
+     * as ((c0 + c1) + (c2 + c3)) + ((r0 + r1) + (r2 + r3)); one p.Ap partial per block row. */
+    if (pl->sub_grid > 0 && pl->sub_n > 0 && pl->sub_dense) {
+        const int nt = pl->sub_n_glob, nb = (nt + 63) / 64, SL = pl->sub_strip;
+        const double *F = pl->sub_full;
+#define FV(i, j) (((i) < nt && (j) < nt) ? F[(size_t)(i) * nt + (j)] : 0.0)
+#define XS(j) ((j) < nt ? xsub[j] : 0.0)
+        for (int B = 0; B < nb; ++B) {
+            double cw[4][64], rw[4][64];
+            memset(cw, 0, sizeof(cw)); memset(rw, 0, sizeof(rw));
+            for (int wv = 0; wv < 4; ++wv) {
+                for (int K = wv; K < B; K += 4)                      /* column sums of tile (K, B): lane c over rows r */
+                    for (int c = 0; c < 64; ++c) {
+                        double ca = 0.0;
+                        for (int r = 0; r < 64; ++r) ca += FV(64 * K + r, 64 * B + c) * XS(64 * K + r);
+                        cw[wv][c] += ca;
+                    }
+                int sidx = 0;
+                for (int J0 = B; J0 < nb; J0 += SL, ++sidx) {        /* strips of block row B */
+                    if ((sidx & 3) != wv) continue;
+                    const int J1 = J0 + SL < nb ? J0 + SL : nb;
+                    for (int r = 0; r < 64; ++r) {
+                        double ra = 0.0;
+                        for (int J = J0; J < J1; ++J)
+                            for (int c = 0; c < 64; ++c) ra += FV(64 * B + r, 64 * J + c) * XS(64 * J + c);
+                        rw[wv][r] += ra;
+                    }
+                }
+            }
+            double dot[BLK];
+            for (int t = 0; t < BLK; ++t) dot[t] = 0.0;
+            for (int l = 0; l < 64; ++l) {
+                const int i = 64 * B + l;
+                if (i >= nt) continue;
+                const double a = ((cw[0][l] + cw[1][l]) + (cw[2][l] + cw[3][l])) + ((rw[0][l] + rw[1][l]) + (rw[2][l] + rw[3][l]));
+                const int r = pl->sub_rows[i];
+                y[r] += a;
+                dot[l] = x[r] * a;
+            }
+            pd[B] = block_sum(dot);
+        }
+#undef FV
+#undef XS
+    } else
     /* ---- sub-block: sub_spmv_kernel (a wave per local sub row; rows s = b 4 + w, + grid 4, ...) */
     if (pl->sub_grid > 0 && pl->sub_n > 0) {
         const int grid = pl->sub_grid;

@@ -39,14 +39,14 @@ def _make(km, torch, xyz, element, charge, cb, metals, n1, layers, comm, nn_dist
     return buf
 
 
-def _device_rank(km, oracle, buf, row0):
+def _device_rank(km, oracle, buf, row0, dense=False):
     """What fixes one rank's summation order + the system as assembled on the device (for oracle.pcg_device_order_ranks)."""
     S = km.solvers
     mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
     plan, v, tn = mat.sum_plan(), S.t_vectors(buf), S.t_tunnel(buf)
     ns = len(tn["row_ptr"]) - 1
     sub = dict(grid=plan["sub_grid"], rows=tn["tunnel_idx"][tn["first"]:tn["first"] + ns] + 2 - row0, row_ptr=tn["row_ptr"],
-               col=tn["col"], val=tn["val"])
+               col=tn["col"], val=tn["val"], dense=dense)
     return dict(rank=oracle.DeviceRank(plan, sub), rhs=v["rhs"], dinv=v["dinv"], ns=ns, variant="cg1r" if plan["cg_variant"] else "classic")
 
 
@@ -389,6 +389,13 @@ def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5
         buf.atom_virtual_potentials.zero_()
         buf.site_power.zero_()
         im, st = S.update_power_gpu_sparse_dist(buf, *args, True, False, 1.0, cg_tolerance=1e-13, cg_max_iterations=20000, **kw)
+        # either storage against the oracle adding in ITS order (bitmap: a wave per row; tiles: strips, row and column
+        # sums, four waves per block row): the same solve, bit for bit (heating on: potentials scaled, then shifted)
+        od = _device_order_solve(oracle, [_device_rank(km, oracle, buf, 0, dense=bool(dense))], [n], [0], 1e-13, 20000)
+        mo = od["x"] * G0
+        mo = mo + abs(min(mo[2:].min(), 0.0))
+        assert st["iterations"] == od["iterations"], (dense, st["iterations"], od["iterations"])
+        np.testing.assert_array_equal(buf.atom_virtual_potentials.cpu().numpy()[:n], mo)
         res[dense] = dict(tn=tn, dinv=v["dinv"], Ap=Ap.cpu().numpy(), x=x, im=im, st=st, m=buf.atom_virtual_potentials.cpu().numpy().copy(),
                           pw=buf.site_power.cpu().numpy().copy(), n=n)
         buf.freeGPUmemory()

@@ -242,10 +242,25 @@ def main():
     # the same matrix re-planned onto the CSR stream kernel (f64 values + i32 columns), timed the same way, then
     # the default plan is restored
     roofline_csr = None
+    roofline_f64 = None
     if world == 1 and minfo["spmv_kind"] == 2:
         saved = {k: os.environ.get(k) for k in ("KMCF_SPMV_KIND", "KMCF_SPMV_CODED")}
-        os.environ["KMCF_SPMV_KIND"], os.environ["KMCF_SPMV_CODED"] = "1", "0"
         try:
+            # what the planner gives a matrix WITHOUT a small value dictionary (general f64 values): the window kernel
+            # with f64 values + 16-bit window slots, 10 B/nnz + 4 B per window column + 20 B/row
+            os.environ["KMCF_SPMV_KIND"], os.environ["KMCF_SPMV_CODED"] = "2", "0"
+            i_w = mat.replan()
+            if i_w["spmv_kind"] == 2 and not i_w["spmv_coded"]:
+                mat.spmv_bench(5, True)
+                us = mat.spmv_bench(args.spmv_reps, True) * 1e3 / args.spmv_reps
+                wb = 10.0 * nnz_loc + 4.0 * i_w["spmv_window_cols"] + 20.0 * n_loc
+                roofline_f64 = {"bound": "hbm", "kernel": "spmv_window_kernel (window SpMV, f64 values + 16-bit slots, fused p.Ap)",
+                                "us_per_launch": round(us, 2), "algorithmic_bytes_per_launch": int(wb),
+                                "achieved": round(wb / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(wb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                "csr_equivalent": {"bytes_per_launch": int(csr_bytes), "frac": round(csr_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                                "fits_infinity_cache": bool(wb + vec_bytes < mall)}
+            os.environ["KMCF_SPMV_KIND"], os.environ["KMCF_SPMV_CODED"] = "1", "0"
             mat.replan()
             if mat.info()["spmv_kind"] == 1:
                 mat.spmv_bench(5, True)
@@ -398,6 +413,7 @@ def main():
             "roofline": roofline,
             "roofline_csr": roofline_csr,
             "roofline_hbm": roofline_hbm,
+            "roofline_f64": roofline_f64,
             "cpu_baseline": cpu,
         }
         if diag is not None:

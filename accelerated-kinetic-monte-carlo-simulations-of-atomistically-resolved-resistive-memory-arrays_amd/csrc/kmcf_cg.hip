@@ -841,6 +841,7 @@ int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, dou
     scale_vector_kernel<<<g, KMCF_BLOCK, 0, c->stream>>>(n, m->d_x, dis, 1);      // start guess (:751)
     KMCF_HIP(hipGetLastError());
     m->coded = false;             // d_val no longer matches the value codes: SpMV reads d_val from here on
+    m->sellv_dirty = true;        // ... through the f64 row-per-lane stream where the matrix has one: refreshed from d_val at the next SpMV
     if (d_rhs_user) KMCF_TRY(kmcf_vec_out(m, d_rhs_user, m->d_r));
     // plain CG on the scaled system; the reference carries r = A y - b and p = -r (:826-836),
     // the same iterates as r = b - A y, p = r used here.  The unpreconditioned loop never

@@ -233,6 +233,12 @@ struct kmcf_matrix {
     int *d_sell_wcol = nullptr;        // column of each window slot
     unsigned short *d_sell = nullptr;  // the entry stream
     int *d_sell_pos = nullptr;         // per row: position of its first entry in d_sell
+    // ... the same layout with f64 VALUES streamed next to the 16-bit slots (spmv_sellv_kernel: matrices whose values are
+    // not dictionary-coded -- general CSR input, the symmetrically scaled CB-edge system): d_sellv[pos] = value of entry pos
+    // of d_sell (0.0 in the padding), refreshed from d_val whenever the values changed; allocated on first use
+    double *d_sellv = nullptr;
+    bool sellv_dirty = true;
+    int sellv_grid = 0;
     int spmv_u = 8;                    // stream: nnz per thread per chunk
     int spmv_lpr2 = 4;                 // stream: lanes per row in the LDS reduction
     int n_chunks = 0;
@@ -289,9 +295,15 @@ inline int kmcf_vec_grid(int n)
 inline bool kmcf_cg_single_reduction(const kmcf_matrix *m);
 
 // grid of the interior SpMV pass = number of p.Ap partials it writes
+inline bool kmcf_sellv_usable(const kmcf_matrix *m)
+{
+    return m->spmv_kind == 2 && !m->coded && m->sell_ok && m->sell_ident && m->sellv_grid > 0;      // (sellv_grid: 0 with KMCF_SPMV_SELLV=0 at plan time)
+}
+
 inline int kmcf_interior_grid(const kmcf_matrix *m)
 {
     if (m->spmv_kind == 2 && m->coded) return (m->sell_ok && m->dict_n <= 3) ? m->sell_grid : m->spmv_grid_coded;
+    if (kmcf_sellv_usable(m)) return m->sellv_grid;
     return m->spmv_grid;
 }
 

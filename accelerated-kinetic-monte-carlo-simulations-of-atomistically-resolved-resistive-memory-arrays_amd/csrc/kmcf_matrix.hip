@@ -463,8 +463,9 @@ extern "C" int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info)
     info->send_rows = m->n_send;
     info->boundary_rows = m->n_boundary_rows;
     info->spmv_kind = m->spmv_kind;
-    const bool sell = m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3;
-    info->spmv_coded = (m->spmv_kind == 2 && m->coded) ? (sell ? 2 : 1) : 0;
+    const bool sellc = m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3;
+    const bool sell = sellc || kmcf_sellv_usable(m);      // either row-per-lane kernel: the lane stream's figures
+    info->spmv_coded = (m->spmv_kind == 2 && m->coded) ? (sellc ? 2 : 1) : 0;
     info->spmv_tiles = m->spmv_kind == 2 ? (sell ? m->n_sell_tiles : m->n_tiles) : 0;
     info->spmv_window_cols = m->spmv_kind == 2 ? (sell ? m->n_sell_wcols : m->n_wcols) : 0;
     info->spmv_stream_entries = sell ? m->n_sell_entries : (info->spmv_coded ? (int64_t)m->h_row_ptr[m->n_short] : 0);

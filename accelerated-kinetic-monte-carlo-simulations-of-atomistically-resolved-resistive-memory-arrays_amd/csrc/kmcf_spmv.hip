@@ -556,6 +556,112 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------ row-per-lane kernel, f64 values
+// The row-per-lane layout for matrices whose values are NOT dictionary-coded (general CSR input; the symmetrically
+// scaled CB-edge system): same tiles, same lane order, same window (the tile's own rows + the outside columns through
+// wcol, staged once in LDS -- plain x here, one copy), same 16-bit entries (LDS byte offsets; the code bits are masked
+// off), and next to them the entries' f64 VALUES in the same [step][lane][4] order: 10 B per entry.  Per entry one
+// ds_read_b64, one multiply, one add -- no products parked in LDS, no second pass over them, no row_ptr: the window
+// kernel (10 B/nnz too) needs both (131 us at 40 nm; this one: see DESIGN 3.1).  Row sum = the off-diagonal products in
+// stored order, then the diagonal product (d_diagv): the order of the coded kernel.  Latency is hidden by occupancy
+// (16 KB of LDS and <= 64 VGPRs per block: 8 blocks per CU), not by a hand-built pipeline: a tile moves 5 x the bytes of
+// a coded tile.
+template <int LW, bool DOT, bool SKIP_BOUNDARY>
+__global__ __launch_bounds__(KMCF_BLOCK) void spmv_sellv_kernel(
+    int n_tiles, const int4 *__restrict__ tile4, const int2 *__restrict__ swave, const int *__restrict__ wcol,
+    const sell_pair *__restrict__ stream, const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
+    const unsigned char *__restrict__ is_boundary, double *__restrict__ part, const kmcf_scalars *__restrict__ S, int check_done,
+    const double *__restrict__ diagv)
+{
+    constexpr int W = 1 << LW, WQ = W / KMCF_BLOCK - 1;
+    constexpr unsigned int OFFMASK = (unsigned int)((W - 1) << 3);
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    __shared__ double xs[2][W];
+    if (check_done && S->done) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int Cx = (n_tiles + 7) >> 3;
+    const int gmax = min(Cx, n_tiles - xcd * Cx);
+    const int nt = gmax > bi ? (gmax - bi + nb8 - 1) / nb8 : 0;
+    double dot = 0.0;
+    int buf = 0;
+    for (int k = 0; k < nt; ++k, buf ^= 1) {
+        const int c = xcd * Cx + bi + k * nb8;
+        const int4 d = tile4[c];                             // (first row, rows, first window slot, outside columns)
+        const int2 sw = swave[c * 4 + wv];                   // (first 8-byte group of this wave's stream, steps)
+        const bool has_row = tid < d.y;
+        const int row = d.x + min(tid, d.y - 1);
+        const double xrow = x[row], dg = diagv[row];
+        double *xb = xs[buf];
+        xb[tid] = has_row ? xrow : 0.0;                      // window slots 0 .. 255: the tile's own rows
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int slot = q * KMCF_BLOCK + tid;
+            xb[KMCF_BLOCK + slot] = slot < d.w ? x[wcol[d.z + slot]] : 0.0;       // (slots past the window, the padding target W - 1 among them: 0.0)
+        }
+        __syncthreads();                                     // (buffer `buf` was last read two tiles ago: every thread has passed the barrier in between)
+        const char *base = reinterpret_cast<const char *>(xb);
+        const sell_pair *sp = stream + sw.x + lane;
+        const dvec2 *vp = reinterpret_cast<const dvec2 *>(vals + ((size_t)sw.x + lane) * 4);
+        double s = 0.0;
+        int q = 0;
+        for (; q + 2 <= sw.y; q += 2) {                      // two steps per trip: their loads in flight together
+            const sell_pair e0 = sp[q * 64], e1 = sp[(q + 1) * 64];
+            const dvec2 a0 = vp[(size_t)q * 128], a1 = vp[(size_t)q * 128 + 1], b0 = vp[(size_t)(q + 1) * 128], b1 = vp[(size_t)(q + 1) * 128 + 1];
+            s += a0.x * *reinterpret_cast<const double *>(base + ((e0.x & 0xffffu) & OFFMASK));
+            s += a0.y * *reinterpret_cast<const double *>(base + ((e0.x >> 16) & OFFMASK));
+            s += a1.x * *reinterpret_cast<const double *>(base + ((e0.y & 0xffffu) & OFFMASK));
+            s += a1.y * *reinterpret_cast<const double *>(base + ((e0.y >> 16) & OFFMASK));
+            s += b0.x * *reinterpret_cast<const double *>(base + ((e1.x & 0xffffu) & OFFMASK));
+            s += b0.y * *reinterpret_cast<const double *>(base + ((e1.x >> 16) & OFFMASK));
+            s += b1.x * *reinterpret_cast<const double *>(base + ((e1.y & 0xffffu) & OFFMASK));
+            s += b1.y * *reinterpret_cast<const double *>(base + ((e1.y >> 16) & OFFMASK));
+        }
+        if (q < sw.y) {
+            const sell_pair e0 = sp[q * 64];
+            const dvec2 a0 = vp[(size_t)q * 128], a1 = vp[(size_t)q * 128 + 1];
+            s += a0.x * *reinterpret_cast<const double *>(base + ((e0.x & 0xffffu) & OFFMASK));
+            s += a0.y * *reinterpret_cast<const double *>(base + ((e0.x >> 16) & OFFMASK));
+            s += a1.x * *reinterpret_cast<const double *>(base + ((e0.y & 0xffffu) & OFFMASK));
+            s += a1.y * *reinterpret_cast<const double *>(base + ((e0.y >> 16) & OFFMASK));
+        }
+        bool valid = has_row;
+        if (SKIP_BOUNDARY) valid = valid && is_boundary[row] == 0;
+        if (valid) {
+            s += dg * xrow;
+            y[row] = s;
+            if (DOT) dot += xrow * s;
+        }
+    }
+    if (DOT) {
+        __syncthreads();
+        double t = block_sum_256(dot, &xs[0][0]);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
+// values of d_val into the row-per-lane order (and the diagonal into d_diagv): whenever the values changed
+template <int LPR>
+__global__ __launch_bounds__(KMCF_BLOCK) void sellv_refresh_kernel(int n, const int *__restrict__ row_ptr, const int *__restrict__ diag_pos,
+                                                                   const double *__restrict__ val, const int *__restrict__ sell_pos,
+                                                                   double *__restrict__ sellv, double *__restrict__ diagv)
+{
+    constexpr int RPB = KMCF_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    for (int r = blockIdx.x * RPB + threadIdx.x / LPR; r < n; r += gridDim.x * RPB) {
+        const int b = row_ptr[r], e = row_ptr[r + 1], dp = diag_pos[r];
+        const int len = e - b - (dp >= 0 ? 1 : 0);
+        const int pos0 = sell_pos[r];
+        if (lane == 0) diagv[r] = dp >= 0 ? val[dp] : 0.0;
+        for (int k = lane; k < len; k += LPR) {
+            const int j = b + k + ((dp >= 0 && b + k >= dp) ? 1 : 0);
+            sellv[(size_t)pos0 + (size_t)(k >> 2) * 256 + (k & 3)] = val[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ vector kernel
 template <int LPR, bool DOT, bool SKIP_BOUNDARY, bool ROW_LIST>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_vec_kernel(
@@ -915,6 +1021,51 @@ int sell_dispatch_any(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_d
 
 inline bool sell_active(const kmcf_matrix *m) { return m->spmv_kind == 2 && m->coded && m->sell_ok && m->dict_n <= 3; }
 
+#define KMCF_SELLV_ARGS(isb, part) \
+    m->n_sell_tiles, m->d_sell_tile, m->d_sell_wave, m->d_sell_wcol, reinterpret_cast<const sell_pair *>(m->d_sell), m->d_sellv, m->d_p, m->d_Ap, \
+        isb, part, m->d_S, chk, m->d_diagv
+
+int sellv_dispatch(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done)
+{
+    constexpr int LW = 10;
+    hipStream_t st = m->comm->stream;
+    const int chk = skip_if_done ? 1 : 0;
+    const bool skipb = (m->n_halo > 0);
+    const unsigned char *isb = skipb ? m->d_is_boundary : nullptr;
+    double *part = with_dot ? m->d_part_a : nullptr;
+    const int grid = launch ? m->sellv_grid : 0;
+    int pc = 0;
+    if (with_dot) {
+        if (skipb) run_or_query(spmv_sellv_kernel<LW, true, true>, launch, &pc, grid, st, KMCF_SELLV_ARGS(isb, part));
+        else run_or_query(spmv_sellv_kernel<LW, true, false>, launch, &pc, grid, st, KMCF_SELLV_ARGS(isb, part));
+    } else {
+        if (skipb) run_or_query(spmv_sellv_kernel<LW, false, true>, launch, &pc, grid, st, KMCF_SELLV_ARGS(isb, part));
+        else run_or_query(spmv_sellv_kernel<LW, false, false>, launch, &pc, grid, st, KMCF_SELLV_ARGS(isb, part));
+    }
+    return pc;
+}
+
+// the f64 row-per-lane stream exists and holds the current values (allocated on first use, refreshed when dirty)
+int sellv_prepare(kmcf_matrix *m)
+{
+    hipStream_t st = m->comm->stream;
+    if (!m->d_sellv) {
+        const size_t n = (size_t)m->n_sell_entries + 128 * 4;
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_sellv), n * sizeof(double)));
+        KMCF_HIP(hipMemsetAsync(m->d_sellv, 0, n * sizeof(double), st));              // the padding entries stay 0.0
+        m->sellv_dirty = true;
+    }
+    if (m->sellv_dirty) {
+        constexpr int LPR = 4;
+        sellv_refresh_kernel<LPR><<<grid_for(m->n_short, KMCF_BLOCK / LPR), KMCF_BLOCK, 0, st>>>(m->n_short, m->d_row_ptr, m->d_diag_pos, m->d_val,
+                                                                                                m->d_sell_pos, m->d_sellv, m->d_diagv);
+        KMCF_HIP(hipGetLastError());
+        m->sellv_dirty = false;
+    }
+    return KMCF_OK;
+}
+
+
 // The stream's value codes follow d_idx16's (which the assembly kernels write): one pass whenever they changed.
 template <int LPR>
 __global__ __launch_bounds__(KMCF_BLOCK) void sell_refresh_kernel(int n, const int *__restrict__ row_ptr,
@@ -993,6 +1144,9 @@ void launch_interior(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     if (sell_active(m)) {
         if (sell_refresh(m) != KMCF_OK) return;
         sell_dispatch_any(m, true, with_dot, skip_if_done);
+    } else if (kmcf_sellv_usable(m)) {
+        if (sellv_prepare(m) != KMCF_OK) return;
+        sellv_dispatch(m, true, with_dot, skip_if_done);
     } else if (m->spmv_kind == 2) {
         window_dispatch_any(m, m->coded ? 1 : 0, true, with_dot, skip_if_done);
     } else if (m->spmv_kind == 1) {
@@ -1112,7 +1266,17 @@ int plan_window(kmcf_matrix *m, int u, int wq, bool judge, bool *ok)
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_code_fail), sizeof(int)));
     m->coded = false;
     *ok = true;
-    if (for_coded) KMCF_TRY(plan_sell(m, col));
+    KMCF_TRY(plan_sell(m, col));                        // (the coded kernel when the values get a dictionary, the f64 one otherwise)
+    m->sellv_grid = 0;
+    if (m->sell_ok && m->sell_ident && m->sell_lw == 10 && env_int("KMCF_SPMV_SELLV", 1) != 0) {
+        int cus = 0;
+        const int per_cu = sellv_dispatch(m, false, true, false);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->comm->device) != hipSuccess) cus = 0;
+        const int resident = per_cu * cus / kmcf_device_share();
+        int g = grid_for(m->n_sell_tiles, 1);
+        if (resident >= 8 && g > resident) g = resident / 8 * 8;
+        m->sellv_grid = g;
+    }
     return KMCF_OK;
 }
 
@@ -1427,6 +1591,7 @@ static bool coding_enabled(const kmcf_matrix *m)
 int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
 {
     m->coded = false;
+    m->sellv_dirty = true;                               // (the caller is about to write new values)
     if (!coding_enabled(m)) return KMCF_OK;
     KMCF_CHECK(nd >= 0 && nd <= KMCF_DICT_MAX, KMCF_ERR_ARG, "value dictionary of %d entries", nd);
     bool same = true;
@@ -1453,6 +1618,7 @@ int kmcf_matrix_set_dictionary(kmcf_matrix *m, const double *h_dict, int nd)
 int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd)
 {
     m->coded = false;
+    m->sellv_dirty = true;                               // d_val holds new values
     if (!coding_enabled(m) || m->n_short == 0) return KMCF_OK;
     hipStream_t st = m->comm->stream;
     KMCF_TRY(kmcf_matrix_set_dictionary(m, h_dict, nd));
@@ -1472,6 +1638,7 @@ int kmcf_matrix_encode_values(kmcf_matrix *m, const double *h_dict, int nd)
 int kmcf_matrix_encode_from_host(kmcf_matrix *m, const double *h_val_internal)
 {
     m->coded = false;
+    m->sellv_dirty = true;
     if (!coding_enabled(m) || m->n_short == 0) return KMCF_OK;
     // distinct off-diagonal values (bit patterns); give up at the first one beyond the dictionary size
     long long dict[KMCF_DICT_MAX];
@@ -1593,7 +1760,7 @@ extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan,
 {
     KMCF_CHECK(m, KMCF_ERR_ARG, "kmcf_matrix_sum_plan: null matrix");
     KMCF_CHECK(m->d_val, KMCF_ERR_STATE, "kmcf_matrix_sum_plan: host-only matrix");
-    const bool sell = sell_active(m);
+    const bool sell = sell_active(m) || kmcf_sellv_usable(m);
     if (plan) {
         memset(plan, 0, sizeof(*plan));
         plan->rows = m->n_loc;
@@ -1602,7 +1769,7 @@ extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan,
         plan->vec_grid = kmcf_vec_grid(m->n_loc);
         plan->sell_active = sell ? 1 : 0;
         plan->sell_ident = m->sell_ident ? 1 : 0;
-        plan->sell_grid = sell ? m->sell_grid : 0;
+        plan->sell_grid = sell ? kmcf_interior_grid(m) : 0;
         plan->sell_tiles = sell ? m->n_sell_tiles : 0;
         plan->boundary_grid = m->n_halo > 0 && m->n_boundary_rows > 0 ? m->spmv_grid_b : 0;
         plan->boundary_lpr = m->spmv_lpr;
@@ -1754,11 +1921,12 @@ void kmcf_sell_refine_order(int n_short, int n_cols, const int *rp, const int *c
 
 void kmcf_sell_free(kmcf_matrix *m)
 {
-    void *ptrs[] = {m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, m->d_sell, m->d_sell_pos};
+    void *ptrs[] = {m->d_sell_tile, m->d_sell_wave, m->d_sell_lrow, m->d_sell_wcol, m->d_sell, m->d_sell_pos, m->d_sellv};
     for (void *p : ptrs)
         if (p) hipFree(p);
     m->d_sell_tile = nullptr; m->d_sell_wave = nullptr; m->d_sell_lrow = nullptr;
-    m->d_sell_wcol = nullptr; m->d_sell = nullptr; m->d_sell_pos = nullptr;
+    m->d_sell_wcol = nullptr; m->d_sell = nullptr; m->d_sell_pos = nullptr; m->d_sellv = nullptr;
+    m->sellv_dirty = true; m->sellv_grid = 0;
     m->sell_ok = false;
     m->n_sell_tiles = 0;
 }

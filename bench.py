@@ -246,15 +246,23 @@ def main():
     if world == 1 and minfo["spmv_kind"] == 2:
         saved = {k: os.environ.get(k) for k in ("KMCF_SPMV_KIND", "KMCF_SPMV_CODED")}
         try:
-            # what the planner gives a matrix WITHOUT a small value dictionary (general f64 values): the window kernel
-            # with f64 values + 16-bit window slots, 10 B/nnz + 4 B per window column + 20 B/row
+            # what the planner gives a matrix WITHOUT a small value dictionary (general f64 values): the row-per-lane
+            # kernel on f64 values (8 B value + 2 B window slot per streamed entry, padding included, + 4 B per window
+            # column + 28 B/row + 48 B per tile), or, where that stream cannot be built, the window kernel
+            # (10 B/nnz + 4 B per window column + 20 B/row)
             os.environ["KMCF_SPMV_KIND"], os.environ["KMCF_SPMV_CODED"] = "2", "0"
             i_w = mat.replan()
             if i_w["spmv_kind"] == 2 and not i_w["spmv_coded"]:
                 mat.spmv_bench(5, True)
                 us = mat.spmv_bench(args.spmv_reps, True) * 1e3 / args.spmv_reps
-                wb = 10.0 * nnz_loc + 4.0 * i_w["spmv_window_cols"] + 20.0 * n_loc
-                roofline_f64 = {"bound": "hbm", "kernel": "spmv_window_kernel (window SpMV, f64 values + 16-bit slots, fused p.Ap)",
+                if i_w["spmv_stream_entries"] > 0:
+                    k64 = "spmv_sellv_kernel (row-per-lane window SpMV, f64 values + 16-bit slots, fused p.Ap)"
+                    wb = (10.0 * i_w["spmv_stream_entries"] + 4.0 * i_w["spmv_window_cols"] + 28.0 * n_loc
+                          + 48.0 * i_w["spmv_tiles"])
+                else:
+                    k64 = "spmv_window_kernel (window SpMV, f64 values + 16-bit slots, fused p.Ap)"
+                    wb = 10.0 * nnz_loc + 4.0 * i_w["spmv_window_cols"] + 20.0 * n_loc
+                roofline_f64 = {"bound": "hbm", "kernel": k64,
                                 "us_per_launch": round(us, 2), "algorithmic_bytes_per_launch": int(wb),
                                 "achieved": round(wb / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(wb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -132,7 +132,8 @@ typedef struct {
     int spmv_coded;           /* values currently dictionary-coded (2 B/nnz): 1 window kernel, 2 row-per-lane kernel */
     int spmv_tiles;           /* window / row-per-lane kernel: number of tiles      */
     int64_t spmv_window_cols; /* the same: sum of the tiles' window sizes           */
-    int64_t spmv_stream_entries; /* coded kernels: 16-bit entries streamed per launch (row-per-lane: padding included) */
+    int64_t spmv_stream_entries; /* coded kernels: 16-bit entries streamed per launch; row-per-lane kernels (coded, or
+                                    spmv_coded==0 with f64 values): entries per launch, padding included; else 0 */
 } kmcf_matrix_info_t;
 int kmcf_matrix_info(const kmcf_matrix *m, kmcf_matrix_info_t *info);
 

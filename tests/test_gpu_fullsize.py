@@ -165,7 +165,15 @@ def test_full_size_current_and_heat(full, km):
     buf.site_charge.zero_()
     S.update_charge_gpu(buf.site_element, buf.site_charge, buf.neigh_idx, buf.N_, buf.nn_, buf.metal_types,
                         buf.num_metal_types_, comm.counts_events, comm.displs_events, comm)
-    S.update_CB_edge_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
+    import time
+    for rep in range(1 + int(os.environ.get("KMCF_T_REPEAT", "0"))):
+        if buf.site_CB_edge is not None:
+            buf.site_CB_edge.zero_()                        # the same start guess every time
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        st_cb = S.update_CB_edge_gpu_sparse(buf, d["N"], NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
+        t.cuda.synchronize()
+        print("CB edge 40 nm%s: %d iterations, %.1f ms (assembly + solve)" % (" again" if rep else "", st_cb["iterations"], (time.perf_counter() - t0) * 1e3))
     el = buf.site_element.cpu().numpy()
     atom = (el != 0) & (el != 1)
     N_atom = int(atom.sum())

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(const int *__
 // never exceed `number` -- rounding at the very end of the list -- the last entry with a positive value is
 // taken.  Returns the index, or -1 if no entry is positive; *acc becomes the cumulative sum before it.
 // Every lane of the (fully active) wave gets both.
-template <int PER>
-__device__ int wave_search(const double *__restrict__ a, int L, double number, double *acc)
+template <int PER, class F>
+__device__ __forceinline__ int wave_search_f(F value_at, int L, double number, double *acc)
 {
     const int lane = threadIdx.x & 63;
     double base = *acc;
@@ -260,7 +260,7 @@ __device__ int wave_search(const double *__restrict__ a, int L, double number, d
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int idx = s0 + lane * PER + k;
-            const double v = idx < L ? a[idx] : 0.0;
+            const double v = idx < L ? value_at(idx) : 0.0;
             if (v > 0.0) { my_last = idx; my_last_acc = run; }
             run += v;
             p[k] = run;
@@ -298,6 +298,11 @@ __device__ int wave_search(const double *__restrict__ a, int L, double number, d
     }
     if (last >= 0) *acc = last_acc;
     return last;
+}
+template <int PER>
+__device__ int wave_search(const double *__restrict__ a, int L, double number, double *acc)
+{
+    return wave_search_f<PER>([a](int idx) { return a[idx]; }, L, number, acc);
 }
 
 // First slot whose inclusive cumulative sum exceeds the drawn number (thrust::upper_bound on the scan,
@@ -437,17 +442,64 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
 // per lane, then the butterfly.
 constexpr int EV_RT = 32;
 constexpr int EV_PB = 1024;                                 // threads of the persistent block
+constexpr int EV_GLDS = 1024;                               // group sums the block keeps in LDS (8.4 M rows; beyond: read from gsum)
+constexpr int EV_BMAX = 512;                                // events per batch
+constexpr int EV_AFF = 2 * 64 + 2;                          // rows an event touches at most (nn <= 64)
+constexpr int EV_TREL = 2048;                               // range of the tile claim mask (tiles above the smallest touched one)
+constexpr int EV_GSLOTS = 16;                               // groups an event may claim on the patched path (a wavefront each)
+constexpr int EV_TP = (EV_AFF + 2 * (EV_PB / 64) - 1) / (2 * (EV_PB / 64));    // tile passes: half a wavefront per claimed tile
+static_assert(EV_AFF <= 255 && EV_RT == 32, "slab ids are bytes, a slab's row mask is one word");
 
+// Cross-lane partners through the VALU (DPP, and gfx950's v_permlane16/32_swap) instead of ds_bpermute: a double from
+// another lane in ~10 cycles instead of the ~130 of a trip through the LDS crossbar -- the sums below are chains of six
+// of them.  Checked against __shfl_xor in tools/lab/xlane_lab.hip.  All lanes of the wavefront must be active.
+typedef unsigned int ev_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ int ev_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int ev_x16_i(int v)             // lane ^ 16
+{
+    const ev_u2 a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 16) ? a.x : a.y);
+}
+__device__ __forceinline__ int ev_x32_i(int v)             // lane ^ 32
+{
+    const ev_u2 a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32) ? a.x : a.y);
+}
+// STEP 32, 16, 8, 2, 1: the value of lane ^ STEP; STEP 4: of lane ^ 7 (row_half_mirror -- DPP has no lane ^ 4)
+template <int STEP>
+__device__ __forceinline__ int ev_partner_i(int v)
+{
+    if constexpr (STEP == 32) return ev_x32_i(v);
+    else if constexpr (STEP == 16) return ev_x16_i(v);
+    else if constexpr (STEP == 8) return ev_dpp_i<0x128>(v);       // row_ror:8
+    else if constexpr (STEP == 4) return ev_dpp_i<0x141>(v);       // row_half_mirror
+    else if constexpr (STEP == 2) return ev_dpp_i<0x4E>(v);        // quad_perm [2,3,0,1]
+    else return ev_dpp_i<0xB1>(v);                                 // quad_perm [1,0,3,2]
+}
+template <int STEP>
+__device__ __forceinline__ double ev_partner(double v)
+{
+    return __hiloint2double(ev_partner_i<STEP>(__double2hiint(v)), ev_partner_i<STEP>(__double2loint(v)));
+}
+// The fixed order of every sum of the row-aligned tree: a butterfly whose steps pair lane l with l^32, l^16, l^8, l^7,
+// l^2, l^1 (every lane ends with the same bits: the pairs are symmetric and + commutes).
 __device__ __forceinline__ double ev_wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += ev_partner<32>(v); v += ev_partner<16>(v); v += ev_partner<8>(v);
+    v += ev_partner<4>(v); v += ev_partner<2>(v); v += ev_partner<1>(v);
     return v;
 }
 __device__ __forceinline__ double ev_half_sum(double v)    // over the 32 lanes of a half wavefront
 {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += ev_partner<16>(v); v += ev_partner<8>(v);
+    v += ev_partner<4>(v); v += ev_partner<2>(v); v += ev_partner<1>(v);
+    return v;
+}
+__device__ __forceinline__ int ev_wave_min(int v)
+{
+    v = min(v, ev_partner_i<32>(v)); v = min(v, ev_partner_i<16>(v)); v = min(v, ev_partner_i<8>(v));
+    v = min(v, ev_partner_i<4>(v)); v = min(v, ev_partner_i<2>(v)); v = min(v, ev_partner_i<1>(v));
     return v;
 }
 // sum of a group's tile sums (a whole wavefront)
@@ -487,7 +539,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void ev_tree_level_kernel(int level, lo
 }
 
 struct event_batch_args {
-    int count, nn, nbatch;
+    int count, nn, nbatch, trel_max;
     long long n_tiles, n_groups;
     double inv_freq;
 };
@@ -498,12 +550,29 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
     int *__restrict__ site_charge, int *__restrict__ evlog, double *__restrict__ totlog, const double *__restrict__ batch_u,
     event_batch_state *__restrict__ state)
 {
+    // Per event, five dependent global round trips (tile sums of the chosen group -> row sums of the chosen tile -> the
+    // row's slots with their ids and types -> j's neighbour ids -> the <= 2 nn neighbour rows) and six barriers; the
+    // sums an event changes are refreshed WITHOUT a further round trip: the row sums of every touched tile and the tile
+    // sums of every touched group are requested together with the neighbour rows, and what the event changes is
+    // patched into them through LDS (the changed rows' new sums pushed into their tile's slab, the new tile sums looked
+    // up by the group's lanes).  Every sum is formed from the same operands in the same order as a fresh build.
     __shared__ int s_ij[3];
     __shared__ int s_stop;
-    __shared__ int s_rows[2 * 64 + 2];                     // rows whose events change: the neighbours of i and of j, i, j
-    __shared__ int s_uniq[2 * 64 + 2];                     // bit 0 / 1: first entry of its tile / group in s_rows
-    __shared__ int s_rmin;                                 // smallest touched row
-    __shared__ unsigned long long s_tmask[32], s_gmask;    // tiles / groups already claimed, relative to s_rmin's
+    __shared__ int s_rows[EV_AFF];                         // rows whose events change: the neighbours of i, of j, then i, j
+    __shared__ int s_uniq[EV_AFF];                         // bit 0 / 1: first entry of its tile / group in s_rows
+    __shared__ int s_min[2];                               // smallest neighbour of i, of j
+    // claims (no two lanes may hammer ONE LDS word with atomics: same-address LDS atomics serialise at ~40 cycles each,
+    // a wavefront of them is a microsecond): tiles through a table with a word per tile above the smallest touched
+    // one (-1, or the entry that owns the tile: conflicts only among the entries of one tile); groups through a
+    // wavefront-local vote, then one atomic per distinct group
+    __shared__ int s_tent[EV_TREL];
+    __shared__ unsigned long long s_gmask[2];              // (two sets used alternately: set ev & 1 is cleared while event ev + 1 runs)
+    __shared__ int s_ngrp[2], s_slow[2];                   // claimed groups; 1: a touched tile or group is out of the claim range
+    __shared__ int s_grp_of[EV_GSLOTS];
+    __shared__ unsigned int s_slabmask[EV_AFF];            // per owning entry: rows of its tile whose sum this event changed
+    __shared__ double s_slab[EV_AFF][EV_RT];               // ... and their new sums
+    __shared__ double s_tnew[EV_AFF];                      // per owning entry: new sum of its tile
+    __shared__ double s_g[EV_GLDS], s_u[EV_BMAX], s_nlog[EV_BMAX];
     const int nn = A.nn, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int NW = EV_PB / 64;
     const int n_aff = 2 * nn + 2;
@@ -513,17 +582,27 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
 #else
 #define EV_TICK(k)
 #endif
-    if (t == EV_PB - 1) s_rmin = INT_MAX;
-    if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
+    if (t < 2) { s_gmask[t] = 0ull; s_ngrp[t] = 0; s_slow[t] = 0; }
+    for (int q = t; q < EV_TREL; q += EV_PB) s_tent[q] = -1;
+    int my_trel = -1;                                      // the table word this thread's entry claimed in the previous event
+    // Held in LDS for the whole batch: the group sums (the top of every selection walk; written through to gsum), the
+    // batch's uniforms and -log(u) of the residence times.  Each is one global round trip less in front of an event.
+    const bool g_lds = A.n_groups <= EV_GLDS;
+    if (g_lds) for (int g = t; g < (int)A.n_groups; g += EV_PB) s_g[g] = gsum[g];
+    const double *gs = g_lds ? s_g : gsum;
+    if (t < A.nbatch) { s_u[t] = batch_u[2 * t]; s_nlog[t] = -log(batch_u[2 * t + 1]); }    // (:479; A.nbatch <= EV_BMAX)
+    const int trel_max = A.trel_max;                       // EV_TREL (tests: smaller, to reach the out-of-range path)
+    __syncthreads();
     for (int ev = 0; ev < A.nbatch; ++ev) {
+        const int par = ev & 1;
         // ---- select (first wavefront): groups -> tiles of the group -> rows of the tile -> slots of the row
         if (t < 64) {
             double sum = 0.0;
-            for (long long g = t; g < A.n_groups; g += 64) sum += gsum[g];
+            for (long long g = t; g < A.n_groups; g += 64) sum += gs[g];
             const double total = ev_wave_sum(sum);
-            const double number = batch_u[2 * ev] * total;
+            const double number = s_u[ev] * total;
             double acc = 0.0;
-            int g = wave_search<4>(gsum, (int)A.n_groups, number, &acc);
+            int g = wave_search<4>(gs, (int)A.n_groups, number, &acc);
             if (g < 0) g = 0;
             const long long b0 = (long long)g * EV_GROUP;
             int b = wave_search<4>(tsum + b0, (int)(b0 + EV_GROUP < A.n_tiles ? EV_GROUP : A.n_tiles - b0), number, &acc);
@@ -531,11 +610,26 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             const long long r0 = tile * EV_RT;
             int r = wave_search<1>(rsum + r0, (int)(r0 + EV_RT < A.count ? EV_RT : A.count - r0), number, &acc);
             const long long row = r0 + (r < 0 ? 0 : r);
-            int k = wave_search<1>(prob + row * nn, nn, number, &acc);
+            // the row's slots together with their neighbour ids and event types: the chosen slot's j and type arrive with
+            // the probabilities instead of one round trip after them -- and the ids ARE row i's share of s_rows
+            const long long sl = row * nn + (lane < nn ? lane : 0);
+            const double pv_l = prob[sl];
+            const int nj_l = neigh[sl], ty_l = (int)type[sl];
+            int k = wave_search_f<1>([pv_l](int) { return pv_l; }, nn, number, &acc);
             if (k < 0) k = 0;
-            const long long id = row * nn + k;
+            const int j = __shfl(nj_l, k, 64), et = __shfl(ty_l, k, 64);
+            const double t_res = s_nlog[ev] / total;                                  // :479; the device decides whether the step goes on
+            const bool last = !(t_res < A.inv_freq);                                  // this event is the step's last
+            if (j >= 0 && !last) {
+                // row i loses all its events (zero_out_events_split, :237-256, through the symmetric lists)
+                const bool mine = lane < nn && nj_l >= 0;
+                if (lane < nn) s_rows[lane] = nj_l;
+                if (mine) { type[sl] = (unsigned char)EV_NULL; prob[sl] = 0.0; }
+                const int mi = ev_wave_min(mine ? nj_l : INT_MAX);
+                if (lane == 0) s_min[0] = mi;
+            }
             if (t == 0) {
-                const int i = (int)row, j = neigh[id], et = (int)type[id];
+                const int i = (int)row;
                 evlog[3 * ev] = s_ij[0] = i;
                 evlog[3 * ev + 1] = s_ij[1] = j;
                 evlog[3 * ev + 2] = s_ij[2] = et;
@@ -545,105 +639,225 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
                     state->done = 2;                           // nothing selectable: the host reports it
                     stop = 1;
                 } else {
-                    if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
-                    else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
-                    else if (et == EV_VDIFF || et == EV_ODIFF) {
-                        const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
-                        const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
-                    }
                     state->n_exec = ev + 1;
-                    const double t_res = -log(batch_u[2 * ev + 1]) / total;          // :479; the device decides whether the step goes on
                     totlog[2 * ev + 1] = t_res;
-                    if (!(t_res < A.inv_freq)) { state->done = 1; stop = 1; }         // this event was the step's last
+                    if (last) { state->done = 1; stop = 1; }
                 }
                 s_stop = stop;
             }
         }
         __syncthreads();
         EV_TICK(0)
-        if (s_stop) break;                                     // (the sums are rebuilt by the next step's build)
         const int i_del = s_ij[0], j_del = s_ij[1];
-        // ---- rows of i and j lose all their events (zero_out_events_split, :237-256, through the symmetric lists)
-        if (t < 2 * nn) {
-            const int srow = t < nn ? i_del : j_del;
-            const long long own = (long long)srow * nn + (t < nn ? t : t - nn);
-            const int n = neigh[own];
-            s_rows[t] = n;
-            if (n >= 0) { type[own] = (unsigned char)EV_NULL; prob[own] = 0.0; atomicMin(&s_rmin, n); }
+        // execute_event (:284-331) by the last thread, beside the others' work: nothing else in this kernel reads the site
+        // arrays, and the same thread executes every event of the batch (program order between two events' swaps)
+        if (t == EV_PB - 1 && j_del >= 0) {
+            const int i = i_del, j = j_del, et = s_ij[2];
+            if (et == EV_GEN) { site_element[i] = EL_OXYGEN_DEFECT; site_element[j] = EL_VACANCY; site_charge[i] = -2; site_charge[j] = 2; }
+            else if (et == EV_REC) { site_element[i] = EL_DEFECT; site_element[j] = EL_O; site_charge[i] = 0; site_charge[j] = 0; }
+            else if (et == EV_VDIFF || et == EV_ODIFF) {
+                const int te = site_element[i]; site_element[i] = site_element[j]; site_element[j] = te;
+                const int tc = site_charge[i]; site_charge[i] = site_charge[j]; site_charge[j] = tc;
+            }
         }
-        if (t == 0) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; atomicMin(&s_rmin, i_del < j_del ? i_del : j_del); }
+        if (s_stop) break;                                     // (the sums are rebuilt by the next step's build)
+        // ---- row j loses all its events too; the other set of bookkeeping words is cleared for the next event
+        if (t < 64) {
+            const bool in = t < nn;
+            const long long own = (long long)j_del * nn + (in ? t : 0);
+            const int n = in ? neigh[own] : -1;
+            if (in) s_rows[nn + t] = n;
+            if (n >= 0) { type[own] = (unsigned char)EV_NULL; prob[own] = 0.0; }
+            const int mj = ev_wave_min(n >= 0 ? n : INT_MAX);
+            if (t == 0) s_min[1] = mj;
+        }
+        if (t == 64) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; }
+        if (t == EV_PB - 1) { s_gmask[par ^ 1] = 0ull; s_ngrp[par ^ 1] = 0; s_slow[par ^ 1] = 0; }
+        if (my_trel >= 0) { s_tent[my_trel] = -1; my_trel = -1; }   // (last read before the previous event's final barrier)
         __syncthreads();
         EV_TICK(1)
-        // ---- a wavefront per neighbour row: drop the slots that point to i or j, add the row up again (four rows per
-        // wavefront and step: their loads are in flight together)
-        for (int e0 = wv; e0 < 2 * nn; e0 += 4 * NW) {
-            int n[4], jj[4];
-            double pv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * NW;
-                n[q] = e < 2 * nn ? s_rows[e] : -1;
-                const long long sl = (long long)(n[q] >= 0 ? n[q] : 0) * nn + (lane < nn ? lane : 0);
-                jj[q] = neigh[sl];
-                pv[q] = prob[sl];
+        // ---- claims: the first entry of a tile / group owns it (the others would only repeat the same sums): a bit per
+        // tile / group relative to the smallest touched row's.  An owner of a tile takes a slab, an owner of a group a slot.
+        const int tmin = min(min(s_min[0], s_min[1]), min(i_del, j_del)) / EV_RT;
+        if (wv <= (n_aff - 1) / 64) {                          // (whole wavefronts: the group vote needs every lane)
+            const int row = t < n_aff ? s_rows[t] : -1;
+            const bool valid = row >= 0;
+            const int tile = valid ? row / EV_RT : 0;
+            const int trel = tile - tmin, grel = tile / EV_GROUP - tmin / EV_GROUP;
+            int u = valid ? 3 : 0;
+            if (valid) {
+                if (trel < trel_max) {
+                    if (atomicCAS(&s_tent[trel], -1, t) != -1) u &= ~1;
+                    else { s_slabmask[t] = 0u; my_trel = trel; }
+                } else s_slow[par] = 1;
+                if (grel >= 64) s_slow[par] = 1;
             }
-#ifdef KMCF_EV_PROFILE
-            asm volatile("" ::"v"(jj[0]), "v"(jj[1]), "v"(jj[2]), "v"(jj[3]), "v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(pv[3]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            EV_TICK(5)
-#endif
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long sl = (long long)(n[q] >= 0 ? n[q] : 0) * nn + lane;
-                const bool mine = n[q] >= 0 && lane < nn;
-                double v = mine ? pv[q] : 0.0;
-                if (mine && (jj[q] == i_del || jj[q] == j_del)) { type[sl] = (unsigned char)EV_NULL; prob[sl] = 0.0; v = 0.0; }
-                v = ev_wave_sum(v);
-                if (lane == 0 && n[q] >= 0) rsum[n[q]] = v;
+            const bool gv = valid && grel < 64;
+            unsigned long long todo = __ballot(gv);
+            bool first = false;
+            while (todo) {
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                const int gl = __builtin_amdgcn_readlane(grel, leader);
+                if (lane == leader) first = true;
+                todo &= ~__ballot(gv && grel == gl);
             }
-            EV_TICK(6)
+            if (gv && !first) u &= ~2;
+            if (first) {
+                if ((atomicOr(&s_gmask[par], 1ull << grel) >> grel) & 1ull) u &= ~2;
+                else {
+                    const int gslot = atomicAdd(&s_ngrp[par], 1);
+                    if (gslot < EV_GSLOTS) s_grp_of[gslot] = tile / EV_GROUP;
+                    else s_slow[par] = 1;
+                }
+            }
+            if (t < n_aff) s_uniq[t] = u;
         }
-        // which entries are the first of their tile / group (the others would only repeat the same sums): a bit per tile /
-        // group relative to the smallest touched row's; whoever sets it first owns it (a tile / group out of the
-        // masks' range is simply added again by every entry that touches it)
-        if (t < n_aff) {
-            const int row = s_rows[t];
-            int u = 0;
-            if (row >= 0) {
-                const int trel = row / EV_RT - s_rmin / EV_RT, grel = row / (EV_RT * EV_GROUP) - s_rmin / (EV_RT * EV_GROUP);
-                u = 3;
-                if (trel < 2048 && (atomicOr(&s_tmask[trel >> 6], 1ull << (trel & 63)) >> (trel & 63)) & 1ull) u &= ~1;
-                if (grel < 64 && (atomicOr(&s_gmask, 1ull << grel) >> grel) & 1ull) u &= ~2;
-            }
-            s_uniq[t] = u;
-        }
+        EV_TICK(7)
         __syncthreads();
         EV_TICK(2)
-        // ---- tile sums: half a wavefront per touched tile
-        for (int e = 2 * wv + (lane >> 5); e < n_aff; e += 2 * NW) {
-            const int row = s_rows[e];
-            const bool on = row >= 0 && (s_uniq[e] & 1);
-            const long long tile = on ? row / EV_RT : 0, rr = tile * EV_RT + (lane & 31);
-            const double v = ev_half_sum(on && rr < A.count ? rsum[rr] : 0.0);
-            if (on && (lane & 31) == 0) tsum[tile] = v;
+        const bool fastp = s_slow[par] == 0;
+        const int ngrp = s_ngrp[par];
+        // ---- requests: eight neighbour rows per wavefront (their ids and probabilities), and with them the row sums of the
+        // claimed tiles (half a wavefront per tile) and the tile sums of the claimed groups (a wavefront per group)
+        int nq[8], jj[8];
+        double pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = wv + NW * q;
+            nq[q] = e < 2 * nn ? s_rows[e] : -1;
+            const long long sl = (long long)(nq[q] >= 0 ? nq[q] : 0) * nn + (lane < nn ? lane : 0);
+            jj[q] = neigh[sl];
+            pv[q] = prob[sl];
+        }
+        double tp[EV_TP], gp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < EV_TP; ++p) {
+            const int e = p * 2 * NW + 2 * wv + (lane >> 5);
+            tp[p] = 0.0;
+            if (fastp && e < n_aff && (s_uniq[e] & 1)) {       // (s_uniq != 0 only for entries with a row)
+                const long long rr = (long long)(s_rows[e] / EV_RT) * EV_RT + (lane & 31);
+                if (rr < A.count) tp[p] = rsum[rr];
+            }
+        }
+        if (fastp && wv < ngrp) {
+            const long long t0 = (long long)s_grp_of[wv] * EV_GROUP + 4 * lane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gp[k] = t0 + k < A.n_tiles ? tsum[t0 + k] : 0.0;
+        }
+#ifdef KMCF_EV_PROFILE
+        asm volatile("" ::"v"(jj[0]), "v"(jj[7]), "v"(pv[0]), "v"(pv[7]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EV_TICK(5)
+#endif
+        // ---- the neighbour rows: drop the slots that point to i or j, add each row up again.  Eight rows in one
+        // butterfly: at offset 32 a lane keeps four rows and hands the other four to its partner, at 16 two and two, at 8
+        // one and one -- every row is added in exactly the pairs of ev_wave_sum (lane l with l ^ 32, then ^ 16, ...), with
+        // 10 exchanges instead of 48; lanes 8 q .. 8 q + 7 end up with row q's sum.
+        double v8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool mine = nq[q] >= 0 && lane < nn;
+            double v = mine ? pv[q] : 0.0;
+            if (mine && (jj[q] == i_del || jj[q] == j_del)) {
+                const long long sl = (long long)nq[q] * nn + lane;
+                type[sl] = (unsigned char)EV_NULL; prob[sl] = 0.0; v = 0.0;
+            }
+            if (nq[q] == i_del || nq[q] == j_del) v = 0.0;  // (their own rows were emptied above)
+            v8[q] = v;
+        }
+        double v4[4], v2[2], v1;
+        {
+            const bool hi = (lane & 32) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double keep = hi ? v8[k + 4] : v8[k], send = hi ? v8[k] : v8[k + 4];
+                v4[k] = keep + ev_partner<32>(send);
+            }
+            const bool h16 = (lane & 16) != 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double keep = h16 ? v4[k + 2] : v4[k], send = h16 ? v4[k] : v4[k + 2];
+                v2[k] = keep + ev_partner<16>(send);
+            }
+            const bool h8 = (lane & 8) != 0;
+            const double keep = h8 ? v2[1] : v2[0], send = h8 ? v2[0] : v2[1];
+            v1 = keep + ev_partner<8>(send);
+            v1 += ev_partner<4>(v1);
+            v1 += ev_partner<2>(v1);
+            v1 += ev_partner<1>(v1);
+        }
+        if ((lane & 7) == 0) {
+            const int e = wv + NW * (lane >> 3);
+            const int nrow = e < 2 * nn ? s_rows[e] : -1;
+            if (nrow >= 0) {
+                rsum[nrow] = v1;
+                if (fastp) {
+                    const int slot = s_tent[nrow / EV_RT - tmin];
+                    s_slab[slot][nrow & (EV_RT - 1)] = v1;
+                    atomicOr(&s_slabmask[slot], 1u << (nrow & (EV_RT - 1)));
+                }
+            }
+        }
+        if (fastp && t >= 64 && t < 66) {                      // rows i and j themselves: sum 0
+            const int r = t == 64 ? i_del : j_del;
+            const int slot = s_tent[r / EV_RT - tmin];
+            s_slab[slot][r & (EV_RT - 1)] = 0.0;
+            atomicOr(&s_slabmask[slot], 1u << (r & (EV_RT - 1)));
+        }
+        __syncthreads();
+        EV_TICK(6)
+        // ---- tile sums: half a wavefront per claimed tile, its rows' sums as requested above with this event's changes
+        // patched in (out-of-range path: per entry, read again)
+        if (fastp) {
+#pragma unroll
+            for (int p = 0; p < EV_TP; ++p) {
+                const int e = p * 2 * NW + 2 * wv + (lane >> 5), l5 = lane & 31;
+                const bool on = e < n_aff && (s_uniq[e] & 1);
+                double val = 0.0;
+                if (on) val = ((s_slabmask[e] >> l5) & 1u) ? s_slab[e][l5] : tp[p];
+                const double v = ev_half_sum(val);
+                if (on && l5 == 0) { tsum[s_rows[e] / EV_RT] = v; s_tnew[e] = v; }
+            }
+            EV_TICK(7)
+        } else {
+            for (int e = 2 * wv + (lane >> 5); e < n_aff; e += 2 * NW) {
+                const int row = s_rows[e];
+                const bool on = row >= 0 && (s_uniq[e] & 1);
+                const long long tile = on ? row / EV_RT : 0, rr = tile * EV_RT + (lane & 31);
+                const double v = ev_half_sum(on && rr < A.count ? rsum[rr] : 0.0);
+                if (on && (lane & 31) == 0) tsum[tile] = v;
+            }
         }
         __syncthreads();
         EV_TICK(3)
-        // ---- group sums: a wavefront per touched group
-        for (int e = wv; e < n_aff; e += NW) {
-            const int row = s_rows[e];
-            if (row < 0 || !(s_uniq[e] & 2)) continue;        // wavefront-uniform
-            const long long g = (row / EV_RT) / EV_GROUP;
-            const double v = ev_group_sum(tsum, g, A.n_tiles);
-            if (lane == 0) gsum[g] = v;
+        // ---- group sums: a wavefront per claimed group, the new tile sums looked up through the claim masks
+        if (fastp) {
+            if (wv < ngrp) {
+                const long long g = s_grp_of[wv];
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long long trel = g * EV_GROUP + 4 * lane + k - tmin;
+                    if (trel >= 0 && trel < trel_max) { const int e = s_tent[trel]; if (e >= 0) gp[k] = s_tnew[e]; }
+                    s += gp[k];
+                }
+                const double v = ev_wave_sum(s);
+                if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
+            }
+        } else {
+            for (int e = wv; e < n_aff; e += NW) {
+                const int row = s_rows[e];
+                if (row < 0 || !(s_uniq[e] & 2)) continue;        // wavefront-uniform
+                const long long g = (row / EV_RT) / EV_GROUP;
+                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
+            }
         }
-        if (t == EV_PB - 1) s_rmin = INT_MAX;                  // (for the next event; nobody reads them in this phase)
-        if (t >= EV_PB - 33) { if (t == EV_PB - 33) s_gmask = 0ull; else s_tmask[t - (EV_PB - 32)] = 0ull; }
         __syncthreads();
         EV_TICK(4)
     }
 #ifdef KMCF_EV_PROFILE
-    if (t == 0) printf("event batch of %d: ticks select %lld zero-own %lld nbr-rows(rest) %lld tiles %lld groups %lld | nbr loads %lld nbr process %lld\n", A.nbatch, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
+    if (t == 0) printf("event batch of %d: ticks select %lld row-j %lld claims %lld nbr-loads %lld nbr-rows %lld tiles %lld groups %lld | before barriers (claims + tiles) %lld\n", A.nbatch, tk[0], tk[1], tk[2], tk[5], tk[6], tk[3], tk[4], tk[7]);
 #endif
 }
 
@@ -813,7 +1027,9 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         } else {
             group_sum_kernel<<<ggrid, KMCF_BLOCK, 0, st>>>(nb, d_tsum, ng, d_gsum);
         }
-        const int BMAX = persistent ? 512 : 128;
+        const int BMAX = persistent ? EV_BMAX : 128;
+        // (KMCF_EV_TREL: tests shrink the claim range to drive the kernel's out-of-range path)
+        const int trel_max = getenv("KMCF_EV_TREL") ? std::min(std::max(atoi(getenv("KMCF_EV_TREL")), 1), EV_TREL) : EV_TREL;
         const bool own_rng = (next_random == kmcf_rng_next);
         if (!w->d_u &&
             (hipMalloc(reinterpret_cast<void **>(&w->d_u), 2 * 512 * sizeof(double)) != hipSuccess ||
@@ -840,7 +1056,7 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                 hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
             if (persistent) {
                 event_batch_args A;
-                A.count = count; A.nn = nn; A.nbatch = nbatch; A.n_tiles = n_tiles2; A.n_groups = n_groups2; A.inv_freq = 1 / freq;
+                A.count = count; A.nn = nn; A.nbatch = nbatch; A.trel_max = trel_max; A.n_tiles = n_tiles2; A.n_groups = n_groups2; A.inv_freq = 1 / freq;
                 event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
                                                             d_site_charge, d_evlog, d_totlog, d_u, d_state);
             }

@@ -56,7 +56,8 @@ def fields5(oracle, dev5, ref5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T_bg,fullscan", [(300.0, False), (150.0, False), (77.0, False), (150.0, True), (300.0, "callback")])
+@pytest.mark.parametrize("T_bg,fullscan", [(300.0, False), (150.0, False), (77.0, False), (150.0, True), (300.0, "callback"),
+                                           (300.0, "narrow"), (300.0, "three_launches")])
 def test_kmc_step_matches_oracle(km, oracle, dev5, ref5, fields5, T_bg, fullscan, monkeypatch):
     """Same potentials in, same generator state in: identical event sequence (i, j, type), identical final
     element / charge state, event time to 1e-12.  T_bg scales the rates: 300 K -> hundreds of events per
@@ -65,7 +66,15 @@ def test_kmc_step_matches_oracle(km, oracle, dev5, ref5, fields5, T_bg, fullscan
     # fullscan: the reference's way of zeroing events (a pass over every slot per event) instead of the
     # neighbour-list shortcut; both must select the same events.  "callback": a caller-supplied uniform source
     # (events then go one per host round trip instead of in pre-drawn batches).
+    # "narrow": the batch kernel with a claim range of one tile, so that events take its out-of-range path (sums read
+    # again instead of patched); "three_launches": the per-event launches the batch kernel replaced.
     use_callback = fullscan == "callback"
+    monkeypatch.delenv("KMCF_EV_TREL", raising=False)
+    monkeypatch.delenv("KMCF_EVENTS_PERSISTENT", raising=False)
+    if fullscan == "narrow":
+        monkeypatch.setenv("KMCF_EV_TREL", "1")
+    if fullscan == "three_launches":
+        monkeypatch.setenv("KMCF_EVENTS_PERSISTENT", "0")
     fullscan = fullscan is True
     if fullscan:
         monkeypatch.setenv("KMCF_EVENTS_FULLSCAN", "1")

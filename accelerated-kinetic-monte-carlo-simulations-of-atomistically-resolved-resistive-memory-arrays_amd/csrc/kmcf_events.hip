@@ -245,6 +245,32 @@ __global__ __launch_bounds__(KMCF_BLOCK) void group_sum_aff_kernel(const int *__
 // never exceed `number` -- rounding at the very end of the list -- the last entry with a positive value is
 // taken.  Returns the index, or -1 if no entry is positive; *acc becomes the cumulative sum before it.
 // Every lane of the (fully active) wave gets both.
+// Lane exchanges of the search through the VALU (DPP) and scalar reads instead of ds_bpermute (see ev_partner below;
+// checked in tools/lab/scan_lab.hip).  All lanes of the wavefront must be active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double ev_dpp0(double v)        // lanes without a source, or outside ROWMASK, receive 0.0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// inclusive scan over the 64 lanes: inside each row of 16 lanes the steps 1, 2, 4, 8, then the totals of the rows before
+__device__ __forceinline__ double ev_scan_incl(double v)
+{
+    v += ev_dpp0<0x111, 0xf>(v);      // row_shr:1
+    v += ev_dpp0<0x112, 0xf>(v);      // row_shr:2
+    v += ev_dpp0<0x114, 0xf>(v);      // row_shr:4
+    v += ev_dpp0<0x118, 0xf>(v);      // row_shr:8
+    v += ev_dpp0<0x142, 0xa>(v);      // row_bcast15: lane 15 of rows 0 / 2 into rows 1 / 3
+    v += ev_dpp0<0x143, 0xc>(v);      // row_bcast31: lane 31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double ev_readlane(double v, int src)   // src: the same in every lane
+{
+    const int sl = __builtin_amdgcn_readfirstlane(src);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), sl), __builtin_amdgcn_readlane(__double2loint(v), sl));
+}
+
 template <int PER, class F>
 __device__ __forceinline__ int wave_search_f(F value_at, int L, double number, double *acc)
 {
@@ -265,15 +291,9 @@ __device__ __forceinline__ int wave_search_f(F value_at, int L, double number, d
             run += v;
             p[k] = run;
         }
-        double incl = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 0.0;
-        const double seg_total = __shfl(incl, 63, 64);
+        const double incl = ev_scan_incl(run);
+        const double excl = ev_dpp0<0x138, 0xf>(incl);        // wave_shr:1 (lane 0: 0.0)
+        const double seg_total = ev_readlane(incl, 63);
         const double mine = base + excl;                      // cumulative sum before this lane's entries
         int cand = INT_MAX;
         double cand_acc = 0.0;
@@ -285,14 +305,14 @@ __device__ __forceinline__ int wave_search_f(F value_at, int L, double number, d
         const unsigned long long hit = __ballot(cand != INT_MAX);
         if (hit) {                                            // lanes own ascending ranges: the lowest lane wins
             const int src = __ffsll((long long)hit) - 1;
-            *acc = __shfl(cand_acc, src, 64);
-            return __shfl(cand, src, 64);
+            *acc = ev_readlane(cand_acc, src);
+            return __builtin_amdgcn_readlane(cand, __builtin_amdgcn_readfirstlane(src));
         }
         const unsigned long long pos = __ballot(my_last >= 0);
         if (pos) {
             const int src = 63 - __clzll((long long)pos);
-            last = __shfl(my_last, src, 64);
-            last_acc = __shfl(mine + my_last_acc, src, 64);
+            last = __builtin_amdgcn_readlane(my_last, __builtin_amdgcn_readfirstlane(src));
+            last_acc = ev_readlane(mine + my_last_acc, src);
         }
         base += seg_total;
     }
@@ -617,7 +637,8 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             const int nj_l = neigh[sl], ty_l = (int)type[sl];
             int k = wave_search_f<1>([pv_l](int) { return pv_l; }, nn, number, &acc);
             if (k < 0) k = 0;
-            const int j = __shfl(nj_l, k, 64), et = __shfl(ty_l, k, 64);
+            const int ks = __builtin_amdgcn_readfirstlane(k);
+            const int j = __builtin_amdgcn_readlane(nj_l, ks), et = __builtin_amdgcn_readlane(ty_l, ks);
             const double t_res = s_nlog[ev] / total;                                  // :479; the device decides whether the step goes on
             const bool last = !(t_res < A.inv_freq);                                  // this event is the step's last
             if (j >= 0 && !last) {

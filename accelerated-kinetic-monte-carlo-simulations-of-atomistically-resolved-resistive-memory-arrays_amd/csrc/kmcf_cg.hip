@@ -26,9 +26,7 @@ namespace {
 
 __device__ __forceinline__ double wave_sum64(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return kmcf_wave_sum64(v);     // (the xor butterfly 32 ... 1; kmcf_internal.hpp)
 }
 
 __device__ __forceinline__ double block_sum(double v, double *lds4)

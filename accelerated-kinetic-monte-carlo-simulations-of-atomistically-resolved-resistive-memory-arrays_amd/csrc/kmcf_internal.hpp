@@ -420,3 +420,46 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
 // caller-order vector -> internal order (dst internal) and back, on the compute stream
 int kmcf_vec_in(kmcf_matrix *m, double *d_internal, const double *d_user);
 int kmcf_vec_out(kmcf_matrix *m, double *d_user, const double *d_internal);
+
+// ---------------------------------------------------------------- wavefront sum without the LDS crossbar
+// v += __shfl_xor(v, off) for off = 32 ... 1 costs twelve ds_bpermute_b32 in a dependent chain (~130 cycles each way)
+// and sits in front of, or behind, the stream of every CG kernel and SpMV.  The same butterfly through the VALU: gfx950's
+// v_permlane32_swap / v_permlane16_swap for lane ^ 32 / ^ 16, DPP row_ror:8 for ^ 8, quad_perm for ^ 2 / ^ 1; for
+// ^ 4 DPP has no pattern, but after the ^ 8 step lanes l and l ^ 8 hold the same bits, so row_ror:4 -- lane
+// (l + 4) mod 16, which is l ^ 4 or l ^ 12 -- delivers the value lane l ^ 4 holds.  Operand for operand the sum of the
+// shuffle loop: the results (and the oracle's device-order restatement, oracle/kmcf_oracle_order.c) do not change.
+// All 64 lanes must be active.  (tools/lab/xlane_lab.hip checks the patterns against __shfl_xor.)
+#if defined(__HIPCC__)
+typedef unsigned int kmcf_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double kmcf_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double kmcf_lane_xor32(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const kmcf_u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool up = (threadIdx.x & 32) != 0;
+    return __hiloint2double((int)(up ? b.x : b.y), (int)(up ? a.x : a.y));
+}
+__device__ __forceinline__ double kmcf_lane_xor16(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const kmcf_u2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = (threadIdx.x & 16) != 0;
+    return __hiloint2double((int)(odd ? b.x : b.y), (int)(odd ? a.x : a.y));
+}
+__device__ __forceinline__ double kmcf_wave_sum64(double v)
+{
+    v += kmcf_lane_xor32(v);
+    v += kmcf_lane_xor16(v);
+    v += kmcf_dpp_f64<0x128>(v);      // row_ror:8  = lane ^ 8
+    v += kmcf_dpp_f64<0x124>(v);      // row_ror:4  : the bits of lane ^ 4 (see above)
+    v += kmcf_dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1] = lane ^ 2
+    v += kmcf_dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2] = lane ^ 1
+    return v;
+}
+#endif

@@ -320,8 +320,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sum_ab_kernel(double *__restrict__
 // ---------------------------------------------------------------- heat
 __device__ __forceinline__ double block_sum_h(double v, double *lds4)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = kmcf_wave_sum64(v);
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);

@@ -73,8 +73,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void p2p_allreduce_parts_kernel(char *c
         double v = 0.0;
         for (int q = 0; q < 4; ++q)
             for (int j = t; j < r.n[q]; j += KMCF_BLOCK) v += r.p[q][j];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        v = kmcf_wave_sum64(v);
         if ((t & 63) == 0) lds4[t >> 6] = v;
         __syncthreads();
         if (t == 0) mine[i] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);

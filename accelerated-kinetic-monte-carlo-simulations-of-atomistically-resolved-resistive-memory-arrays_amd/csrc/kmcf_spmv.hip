@@ -46,7 +46,7 @@ __device__ __forceinline__ double wave_sum_width(double v, int width)
 // Deterministic block sum (256 threads): shuffle inside each wavefront, then LDS.
 __device__ __forceinline__ double block_sum_256(double v, double *lds4)
 {
-    v = wave_sum_width(v, 64);
+    v = kmcf_wave_sum64(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) lds4[w] = v;
     __syncthreads();

@@ -88,12 +88,7 @@ __device__ __forceinline__ double dist3(double x1, double y1, double z1, double 
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return kmcf_wave_sum64(v); }
 
 __device__ __forceinline__ double block_sum4(double v, double *lds4)
 {

@@ -358,7 +358,7 @@ def main():
     if world == 1 and os.path.exists(tpath):
         tj = json.load(open(tpath))
         entries = tj["kernels"] if "kernels" in tj else [tj]
-        for blk in (roofline, roofline_csr, roofline_hbm):
+        for blk in (roofline, roofline_csr, roofline_hbm, roofline_f64):
             if blk is None or "kernel" not in blk:
                 continue
             for e in entries:

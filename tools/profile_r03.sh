@@ -25,7 +25,7 @@ echo "== extras"
 E=$OUT/extras; mkdir -p $E
 KMCF_T_REPEAT=2 rocprofv3 --kernel-trace --stats -d $E/tpath -o t --output-format csv -- \
     python3 -m pytest $R/tests/test_gpu_fullsize.py::test_full_size_current_and_heat -x -q -s > $E/tpath.log 2>&1
-grep "T 40 nm" $E/tpath.log > $E/tpath_40nm.txt
+grep "T 40 nm\|CB edge" $E/tpath.log > $E/tpath_40nm.txt
 KMCF_T_FULL_WINDOW=1 python3 -m pytest $R/tests/test_gpu_fullsize.py::test_full_size_current_and_heat -x -q -s 2>&1 | grep "T 40 nm\|passed\|failed" > $E/tpath_40nm_reference_window.txt
 python3 $R/tools/kmc_loop.py --workload 40nm --T 77 --steps 3 > $E/kmc_loop_40nm.txt 2>&1
 KMCF_EVENTS_PERSISTENT=0 python3 $R/tools/kmc_loop.py --workload 40nm --T 77 --steps 3 > $E/kmc_loop_40nm_three_launches.txt 2>&1

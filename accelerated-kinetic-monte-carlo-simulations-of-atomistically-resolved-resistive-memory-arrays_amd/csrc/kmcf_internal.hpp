@@ -427,7 +427,7 @@ int kmcf_vec_out(kmcf_matrix *m, double *d_user, const double *d_internal);
 // v_permlane32_swap / v_permlane16_swap for lane ^ 32 / ^ 16, DPP row_ror:8 for ^ 8, quad_perm for ^ 2 / ^ 1; for
 // ^ 4 DPP has no pattern, but after the ^ 8 step lanes l and l ^ 8 hold the same bits, so row_ror:4 -- lane
 // (l + 4) mod 16, which is l ^ 4 or l ^ 12 -- delivers the value lane l ^ 4 holds.  Operand for operand the sum of the
-// shuffle loop: the results (and the oracle's device-order restatement, oracle/kmcf_oracle_order.c) do not change.
+// shuffle loop: the results (and with them the device-order restatement the tests compare with) do not change.
 // All 64 lanes must be active.  (tools/lab/xlane_lab.hip checks the patterns against __shfl_xor.)
 #if defined(__HIPCC__)
 typedef unsigned int kmcf_u2 __attribute__((ext_vector_type(2)));

@@ -1051,6 +1051,10 @@ extern "C" int kmcf_tstate_info(const kmcf_tstate *t, kmcf_tstate_info_t *info)
     info->tunnel_points_rank = t->assembled ? t->sub.n_loc : 0;
     info->tunnel_first = t->assembled ? t->sub.row0 : 0;
     info->nnz_tunnel = t->assembled ? t->sub.nnz : 0;
+    info->tunnel_dense = t->assembled && t->sub.dense ? 1 : 0;
+    info->tunnel_bytes = !t->assembled ? 0
+                         : t->sub.dense ? (int64_t)t->sub.n_tiles * 4096 * 8
+                                        : (int64_t)t->sub.nnz * 8 + (int64_t)t->sub.n_loc * ((t->sub.n_glob + 63) / 64) * 8;
     return KMCF_OK;
 }
 
@@ -1212,9 +1216,17 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
         KMCF_HIP(hipMemcpyAsync(pin_nnz, sb.d_voff + ns, sizeof(long long), hipMemcpyDeviceToHost, st));
         KMCF_HIP(hipStreamSynchronize(st));
         sb.nnz = *pin_nnz;
-        // storage of the block: dense symmetric tiles for one rank when the block is more than half full (half the bytes
-        // of the packed full block per application), else the bitmap + packed values.  KMCF_SUB_DENSE=0 / 1 overrides.
-        sb.dense = P == 1 && n_t >= 2048 && 2.0 * (double)sb.nnz > (double)n_t * (double)n_t;
+        // storage of the block: dense symmetric tiles for one rank when the block is more than a QUARTER full, else the
+        // bitmap + packed values.  In bytes the tiles (4 n^2) win from half full on (8 d n^2 + n^2 / 8 for the bitmap
+        // form); in time from a quarter on: the tile kernel streams at 5.3 TB/s, the bitmap kernel -- a load of 64 x d
+        // values per mask word -- at 2.7 (the reference's contact window at 40 nm, 44 % full: 3.8 against 6.3 ms per
+        // application).  Not when the tiles would take more than 60 % of the free device memory.  KMCF_SUB_DENSE=0 / 1 overrides.
+        sb.dense = P == 1 && n_t >= 2048 && 4.0 * (double)sb.nnz > (double)n_t * (double)n_t;
+        if (sb.dense && sb.cap_tiles < (size_t)((long long)((n_t + 63) / 64) * ((n_t + 63) / 64 + 1) / 2) * 4096) {
+            size_t fr = 0, tot = 0;
+            const double need = 4.0 * (double)n_t * (double)n_t + 1024.0 * ((double)n_t / 64) * ((double)n_t / 64) / 2;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > 0.6 * (double)fr) sb.dense = false;
+        }
         if (const char *e = getenv("KMCF_SUB_DENSE")) sb.dense = P == 1 && atoi(e) != 0;
         if ((n_t + 63) / 64 > KMCF_MAX_PARTIALS) sb.dense = false;       // (one p.Ap partial per block row)
         if (sb.dense) {

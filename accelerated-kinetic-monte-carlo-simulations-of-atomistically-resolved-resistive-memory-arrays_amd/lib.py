@@ -35,7 +35,7 @@ class SumPlan(C.Structure):
 class TStateInfo(C.Structure):
     _fields_ = [("N_atom", C.c_int), ("Nsub", C.c_int), ("rows_this_rank", C.c_int), ("nnz_neighbour", C.c_int64),
                 ("tunnel_points", C.c_int), ("tunnel_points_rank", C.c_int), ("tunnel_first", C.c_int),
-                ("nnz_tunnel", C.c_int64)]
+                ("nnz_tunnel", C.c_int64), ("tunnel_dense", C.c_int), ("tunnel_bytes", C.c_int64)]
 
 
 class CurrentParams(C.Structure):

@@ -385,6 +385,8 @@ typedef struct {
     int tunnel_points_rank; /* counts_subblock[rank]                                 */
     int tunnel_first;       /* displ_subblock[rank]                                  */
     int64_t nnz_tunnel;     /* this rank's rows of the tunnel sub-block              */
+    int tunnel_dense;       /* 1: stored as dense symmetric 64 x 64 tiles (one rank, block more than a quarter full), 0: bitmap + packed values */
+    int64_t tunnel_bytes;   /* bytes one application of the sub-block streams in that storage */
 } kmcf_tstate_info_t;
 int kmcf_tstate_info(const kmcf_tstate *t, kmcf_tstate_info_t *info);
 /* Exports for tests / inspection.  Pattern: rows of this rank, GLOBAL columns ascending (pass

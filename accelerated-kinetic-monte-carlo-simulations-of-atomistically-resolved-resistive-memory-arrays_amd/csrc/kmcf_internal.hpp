@@ -421,6 +421,18 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
 int kmcf_vec_in(kmcf_matrix *m, double *d_internal, const double *d_user);
 int kmcf_vec_out(kmcf_matrix *m, double *d_user, const double *d_internal);
 
+// ---------------------------------------------------------------- stream of the set-up kernels that read the caller's arrays
+// Set-up functions (pattern builds, neighbour lists) launch the kernels that read the CALLER's coordinate arrays on the
+// caller's own stream, not on the communicator's.  Found with in-process test groups (several host threads, each with
+// its torch tensors uploaded a moment ago from pageable memory): a kernel on the communicator's non-blocking stream saw
+// such an array as it was BEFORE the upload (zeros of the fresh allocation) although the upload call had returned, a
+// synchronous copy of the same array at entry saw the uploaded values, and neither an event on the caller's stream nor
+// a hipDeviceSynchronize() at entry changed that; the same kernel on the caller's stream, or after a synchronous
+// device-to-device copy into a buffer of the library's, always saw the upload (tools/tmulti_stress.py: 5 wrong builds
+// in 40 rounds before, 0 in 60 after).  Whatever orders an upload from pageable memory in this runtime, it is the stream
+// the upload was issued on.
+inline hipStream_t kmcf_setup_stream(const kmcf_comm *c) { return c->caller_stream; }
+
 // ---------------------------------------------------------------- wavefront sum without the LDS crossbar
 // v += __shfl_xor(v, off) for off = 32 ... 1 costs twelve ds_bpermute_b32 in a dependent chain (~130 cycles each way)
 // and sits in front of, or behind, the stream of every CG kernel and SpMV.  The same butterfly through the VALU: gfx950's

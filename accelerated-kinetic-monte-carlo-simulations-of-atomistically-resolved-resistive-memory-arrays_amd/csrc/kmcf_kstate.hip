@@ -374,13 +374,13 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
     host_cells hc;
     KMCF_TRY(build_cells(d_x, d_y, d_z, N, h_lattice, pbc, nn_dist, &hc));
     int rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left, N_left + N_interface,
-                           &k->h_row_ptr, &k->h_col, c->stream);
+                           &k->h_row_ptr, &k->h_col, kmcf_setup_stream(c));
     if (rc == KMCF_OK)
         rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, 0, N_left,
-                           &k->h_left_row_ptr, &k->h_left_col, c->stream);          // :449-461
+                           &k->h_left_row_ptr, &k->h_left_col, kmcf_setup_stream(c));          // :449-461
     if (rc == KMCF_OK)
         rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left + N_interface, N,
-                           &k->h_right_row_ptr, &k->h_right_col, c->stream);        // :463-474
+                           &k->h_right_row_ptr, &k->h_right_col, kmcf_setup_stream(c));        // :463-474
     hc.release();
     if (rc != KMCF_OK) { delete k; return rc; }
 
@@ -707,15 +707,16 @@ extern "C" int kmcf_neighbor_list(kmcf_comm *c, const double *d_x, const double 
     KMCF_TRY(build_cells(d_x, d_y, d_z, N, lattice, 0, nn_dist, &hc));
     int *d_over = nullptr;
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_over), sizeof(int)));
-    KMCF_HIP(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+    hipStream_t ss = kmcf_setup_stream(c);                       // (the caller's stream: see kmcf_internal.hpp)
+    KMCF_HIP(hipMemsetAsync(d_over, 0, sizeof(int), ss));
     if (count > 0) {
-        neighbor_list_kernel<<<grid1d(count, 1 << 20), KMCF_BLOCK, 0, c->stream>>>(
+        neighbor_list_kernel<<<grid1d(count, 1 << 20), KMCF_BLOCK, 0, ss>>>(
             hc.g, hc.d_cell_start, hc.d_cell_items, d_x, d_y, d_z, nn_dist, N, nn, count, displ, d_neigh_idx, d_over);
         KMCF_HIP(hipGetLastError());
     }
     int over = 0;
-    KMCF_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    KMCF_HIP(hipStreamSynchronize(c->stream));
+    KMCF_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, ss));
+    KMCF_HIP(hipStreamSynchronize(ss));
     hipFree(d_over);
     hc.release();
     KMCF_CHECK(!over, KMCF_ERR_ARG, "kmcf_neighbor_list: a site has more than %d neighbours within nn_dist", NL_CAP);

@@ -934,7 +934,10 @@ extern "C" int kmcf_initialize_sparsity_T(kmcf_comm *c, const double *d_site_x, 
     KMCF_TRY(dalloc(&t->d_ax, (size_t)Na)); KMCF_TRY(dalloc(&t->d_ay, (size_t)Na)); KMCF_TRY(dalloc(&t->d_az, (size_t)Na));
     KMCF_TRY(dalloc(&t->d_acb, (size_t)Na)); KMCF_TRY(dalloc(&t->d_ael, (size_t)Na)); KMCF_TRY(dalloc(&t->d_ach, (size_t)Na));
     KMCF_TRY(dalloc(&t->d_acls, (size_t)Na));
-    gather_coords_kernel<<<grid1d(Na), KMCF_BLOCK, 0, st>>>(Na, t->d_atom_site, d_site_x, d_site_y, d_site_z, t->d_ax, t->d_ay, t->d_az);
+    // On the CALLER's stream (kmcf_setup_stream, kmcf_internal.hpp): the first kernel that reads the caller's arrays.
+    gather_coords_kernel<<<grid1d(Na), KMCF_BLOCK, 0, kmcf_setup_stream(c)>>>(Na, t->d_atom_site, d_site_x, d_site_y, d_site_z, t->d_ax, t->d_ay, t->d_az);
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipStreamSynchronize(kmcf_setup_stream(c)));
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipStreamSynchronize(st));
     std::vector<double> ax((size_t)Na), ay((size_t)Na), az((size_t)Na);

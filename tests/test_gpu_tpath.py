@@ -11,6 +11,8 @@ iteration count and potentials IDENTICAL; against the oracle's natural order: it
 converged solution's TRUE residual <= 3 x the oracle's own true residual."""
 import threading
 
+import os
+
 import numpy as np
 import pytest
 

@@ -706,9 +706,12 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         for (int q = 0; q < 8; ++q) {
             const int e = wv + NW * q;
             nq[q] = e < 2 * nn ? s_rows[e] : -1;
-            const long long sl = (long long)(nq[q] >= 0 ? nq[q] : 0) * nn + (lane < nn ? lane : 0);
-            jj[q] = neigh[sl];
-            pv[q] = prob[sl];
+            jj[q] = -1; pv[q] = 0.0;
+            if (nq[q] >= 0) {                                   // (wavefront-uniform: no requests for empty entries)
+                const long long sl = (long long)nq[q] * nn + (lane < nn ? lane : 0);
+                jj[q] = neigh[sl];
+                pv[q] = prob[sl];
+            }
         }
         // ---- claims: the first entry of a tile / group owns it (the others would only repeat the same sums): a bit per
         // tile / group relative to the smallest touched row's.  An owner of a tile takes a slab, an owner of a group a slot.

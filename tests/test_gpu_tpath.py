@@ -263,6 +263,51 @@ def test_5nm_device(km, oracle, dev5, ref5, torch):
     comm.close()
 
 
+def test_inprocess_builds_read_what_was_uploaded(km, oracle, torch):
+    """Regression ("the flake of the in-process groups"): three host threads upload their site arrays from
+    pageable memory and build their rows of T at once, round after round, on device memory that was filled with junk
+    and handed back before every round -- so that a kernel reading an array as it was BEFORE its upload gets visibly
+    wrong coordinates instead of last round's identical ones.  Before the set-up kernels moved to the caller's stream
+    one round in eight built a wrong pattern."""
+    S = km.solvers
+    d = small_device(seed=11)
+    metals = np.array([TI, N_EL], np.int32)
+    a = 2.5
+    x_lo, x_hi = (d["layers"] - 1) * a - 0.1, (d["layers"] + 7) * a + 0.1
+    T = oracle.TSystem(d["xyz"], d["element"], d["charge"], d["cb"], metals, PAR["nn_dist"], d["n1"], d["n1"], d["layers"],
+                       PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], PAR["tol"], PAR["m_e"], PAR["V0"], x_lo, x_hi)
+    N, P = len(d["element"]), 3
+    for rnd in range(16):
+        junk = [torch.randint(0, 300, ((64 << 20) // 4,), dtype=torch.int32, device="cuda"),
+                torch.rand((32 << 20) // 8, dtype=torch.float64, device="cuda") * 30.0]
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
+        comms = S.KMC_comm.loopback_group(T.Nsub, T.Nsub, N, N, P)
+        errs = []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(0)
+                buf = _make(km, torch, d["xyz"], d["element"], d["charge"], d["cb"], metals, d["n1"], d["layers"], comms[r])
+                r0, nr = int(comms[r].displs_T[r]), int(comms[r].counts_T[r])
+                rp, col = S.t_pattern(buf)
+                np.testing.assert_array_equal(rp, T.row_ptr[r0:r0 + nr + 1] - T.row_ptr[r0])
+                np.testing.assert_array_equal(col, T.col[T.row_ptr[r0]:T.row_ptr[r0 + nr]])
+                buf.freeGPUmemory()
+            except Exception as e:  # pragma: no cover
+                errs.append("round %d, rank %d: %s" % (rnd, r, str(e)[:600]))
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        for c in comms:
+            c.close()
+        assert not errs, "\n".join(errs)
+
+
 @pytest.mark.parametrize("transport", ["loopback", "p2p"])
 @pytest.mark.parametrize("P", [2, 3])
 def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):

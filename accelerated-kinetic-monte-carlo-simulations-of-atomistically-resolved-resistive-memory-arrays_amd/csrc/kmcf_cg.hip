@@ -284,6 +284,44 @@ __global__ __launch_bounds__(KMCF_BLOCK) void cg_tail_kernel(part_ref prz, kmcf_
 
 int vec_grid(int n) { return kmcf_vec_grid(n); }
 
+// End of a chunk of iterations: has the loop stopped?  The device says so in pinned host memory (one thread, behind the
+// chunk's last kernel): {done, iterations, this check's number} -- and the host polls the number instead of sleeping in
+// hipStreamSynchronize, whose wake-up costs more than the ten iterations a small system runs meanwhile (5 nm device:
+// 13 checks per cold solve).  After 3 ms without an answer it sleeps in
+// hipStreamSynchronize after all; KMCF_CG_SYNC=stream: always.
+__global__ void cg_mark_kernel(const kmcf_scalars *__restrict__ S, int *__restrict__ host3, int number)
+{
+    if (threadIdx.x != 0) return;
+    host3[0] = S->done;
+    host3[1] = S->iters;
+    __threadfence_system();
+    __hip_atomic_store(&host3[2], number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int cg_chunk_check(kmcf_comm *c, const kmcf_scalars *S, hipStream_t st, bool *done)
+{
+    static const bool use_stream = getenv("KMCF_CG_SYNC") && strcmp(getenv("KMCF_CG_SYNC"), "stream") == 0;
+    if (use_stream) {
+        KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        KMCF_HIP(hipStreamSynchronize(st));
+        *done = c->h_pinned[0] != 0;
+        return KMCF_OK;
+    }
+    const int number = ++c->mark_seq;
+    cg_mark_kernel<<<1, 64, 0, st>>>(S, c->h_pinned, number);
+    KMCF_HIP(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile int *flag = c->h_pinned + 2;
+    int spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != number) {
+        if ((++spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3e-3) {
+            KMCF_HIP(hipStreamSynchronize(st));            // (then the mark has been written)
+            break;
+        }
+    }
+    *done = c->h_pinned[0] != 0;
+    return KMCF_OK;
+}
+
 // Reads back the scalars of the solve enqueued last (after ONE stream synchronisation) and fills `stats`.
 int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *stats)
 {
@@ -375,11 +413,7 @@ int pcg_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, int absolu
             }
         }
         launched += chunk;
-        if (check_tol) {
-            KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-            KMCF_HIP(hipStreamSynchronize(st));
-            done = c->h_pinned[0] != 0;
-        }
+        if (check_tol) KMCF_TRY(cg_chunk_check(c, S, st, &done));
     }
     if (direct) {       // one SpMV (put, consumption, acknowledgement) per iteration that went on
         const u64 executed = done ? (u64)c->h_pinned[1] : (u64)launched;
@@ -720,11 +754,7 @@ int pcg1_loop(kmcf_matrix *m, double tol, int max_it, int fixed_iters, kmcf_solv
             KMCF_HIP(hipGetLastError());
         }
         launched += chunk;
-        if (check_tol) {
-            KMCF_HIP(hipMemcpyAsync(c->h_pinned, &S->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-            KMCF_HIP(hipStreamSynchronize(st));
-            done = c->h_pinned[0] != 0;
-        }
+        if (check_tol) KMCF_TRY(cg_chunk_check(c, S, st, &done));
     }
     if (p2p_red && !fused) kmcf_p2p_set_red_seq(c, red0 + (done ? (u64)c->h_pinned[1] + 1 : (u64)launched));   // (skipped ones: no number)
     if (fused) {

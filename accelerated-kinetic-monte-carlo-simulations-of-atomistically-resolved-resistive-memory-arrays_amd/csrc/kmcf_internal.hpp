@@ -107,6 +107,7 @@ struct kmcf_comm {
     void *nccl_red = nullptr;           // ncclComm_t: all-reduce / gathers (compute stream)
     bool force_collectives = false;     // KMCF_FORCE_COMM: 1-rank group still runs the collectives
     bool connected = false;
+    int mark_seq = 0;                   // number of the last chunk check (cg_chunk_check)
     int *h_pinned = nullptr;            // 16 ints pinned host (done/iters read-back)
     kmcf_scalars *h_scal = nullptr;     // pinned host copy of a solve's scalars (read after the call's one sync)
     // event-step workspace kept between KMC steps (kmcf_execute_kmc_step, kmcf_events.hip)

@@ -17,6 +17,7 @@
 // returned time).  Ranks own contiguous site ranges; the partial totals are all-gathered and the rank
 // whose range holds the drawn number selects (MPI_Allgather + MPI_Bcast in the reference, :423-470).
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <random>
 #include <vector>
@@ -38,6 +39,8 @@ struct kmcf_event_cache {
     double *d_u = nullptr, *d_totlog = nullptr;     // batch: uniforms in, totals out
     int *d_evlog = nullptr;
     void *d_state = nullptr;
+    char *h_pin = nullptr;                          // persistent batches: state | event log | totals | uniforms, pinned, written / read by the kernel itself
+    int batch_number = 0;
     // row-aligned sum tree of the persistent batch kernel: one sum per row (nn slots), per tile of EV_RT rows, per
     // group of EV_GROUP tiles
     double *d_rsum = nullptr, *d_tsum2 = nullptr, *d_gsum2 = nullptr;
@@ -58,6 +61,7 @@ void kmcf_event_cache_free(kmcf_comm *c)
                     w->d_u, w->d_totlog, w->d_evlog, w->d_state, w->d_neigh_full, w->d_rsum, w->d_tsum2, w->d_gsum2};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (w->h_pin) hipHostFree(w->h_pin);
     delete w;
     c->ev_cache = nullptr;
 }
@@ -339,6 +343,8 @@ __device__ int wave_search(const double *__restrict__ a, int L, double number, d
 struct event_batch_state {
     int done;      // 0 running, 1 the last executed event ended the step, 2 no event could be selected
     int n_exec;    // events executed in this batch
+    int seq;       // batch kernel: the number of the batch, written last (the host polls it: pinned host memory)
+    int pad_;
 };
 
 template <bool FUSED>
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void ev_tree_level_kernel(int level, lo
 }
 
 struct event_batch_args {
-    int count, nn, nbatch, trel_max;
+    int count, nn, nbatch, trel_max, number;
     long long n_tiles, n_groups;
     double inv_freq;
 };
@@ -883,6 +889,11 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         __syncthreads();
         EV_TICK(4)
     }
+    // the batch's results are in the host's memory (evlog, totlog, state: pinned, written by this thread): its number last
+    if (t == 0 && A.number) {
+        __threadfence_system();
+        __hip_atomic_store(&state->seq, A.number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #ifdef KMCF_EV_PROFILE
     if (t == 0) printf("event batch of %d: ticks select %lld row-j %lld claims %lld nbr-loads %lld nbr-rows %lld tiles %lld groups %lld | before barriers (claims + tiles) %lld\n", A.nbatch, tk[0], tk[1], tk[2], tk[5], tk[6], tk[3], tk[4], tk[7]);
 #endif
@@ -1066,8 +1077,20 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         double *d_u = w->d_u, *d_totlog = w->d_totlog;
         int *d_evlog = w->d_evlog;
         event_batch_state *d_state = static_cast<event_batch_state *>(w->d_state);
-        std::vector<double> h_u(2 * BMAX), h_tot(2 * BMAX);
-        std::vector<int> h_log(3 * BMAX);
+        // Persistent batches hand their results over in pinned host memory, which the kernel writes itself and the host
+        // polls (state.seq): no copies in either direction, no sleep in hipStreamSynchronize per batch (a one-event step
+        // of the 5 nm device: 0.15 -> see DESIGN 8).  KMCF_EVENTS_PINNED=0: device buffers and copies.
+        const bool pinned = persistent && !(getenv("KMCF_EVENTS_PINNED") && atoi(getenv("KMCF_EVENTS_PINNED")) == 0);
+        constexpr size_t PIN_LOG = 64, PIN_TOT = PIN_LOG + 3 * EV_BMAX * sizeof(int), PIN_U = PIN_TOT + 2 * EV_BMAX * sizeof(double),
+                         PIN_END = PIN_U + 2 * EV_BMAX * sizeof(double);
+        if (pinned && !w->h_pin && hipHostMalloc(reinterpret_cast<void **>(&w->h_pin), PIN_END, hipHostMallocDefault) != hipSuccess) fail(KMCF_ERR_HIP);
+        std::vector<double> h_u_v(2 * BMAX), h_tot_v(2 * BMAX);
+        std::vector<int> h_log_v(3 * BMAX);
+        const bool pin_ok = pinned && w->h_pin;
+        volatile event_batch_state *p_state = pin_ok ? reinterpret_cast<volatile event_batch_state *>(w->h_pin) : nullptr;
+        double *h_u = pin_ok ? reinterpret_cast<double *>(w->h_pin + PIN_U) : h_u_v.data();
+        double *h_tot = pin_ok ? reinterpret_cast<double *>(w->h_pin + PIN_TOT) : h_tot_v.data();
+        int *h_log = pin_ok ? reinterpret_cast<int *>(w->h_pin + PIN_LOG) : h_log_v.data();
         int B = own_rng ? 4 : 1;
         while (rc == KMCF_OK && t < 1 / freq && nev < max_events) {                      // :418
             const int nbatch = std::min(B, max_events - nev);
@@ -1078,14 +1101,21 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                 h_u[0] = next_random(rng_user);                                           // :430
                 h_u[1] = next_random(rng_user);                                           // :479
             }
-            event_batch_state hs = {0, 0};
-            if (hipMemcpyAsync(d_u, h_u.data(), 2 * nbatch * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-                hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            event_batch_state hs = {0, 0, 0, 0};
+            if (pin_ok) {
+                p_state->done = 0; p_state->n_exec = 0;
+            } else if (hipMemcpyAsync(d_u, h_u, 2 * nbatch * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+                       hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
             if (persistent) {
                 event_batch_args A;
                 A.count = count; A.nn = nn; A.nbatch = nbatch; A.trel_max = trel_max; A.n_tiles = n_tiles2; A.n_groups = n_groups2; A.inv_freq = 1 / freq;
-                event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
-                                                            d_site_charge, d_evlog, d_totlog, d_u, d_state);
+                A.number = pin_ok ? ++w->batch_number : 0;
+                if (pin_ok)
+                    event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
+                                                                d_site_charge, h_log, h_tot, h_u, const_cast<event_batch_state *>(p_state));
+                else
+                    event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
+                                                                d_site_charge, d_evlog, d_totlog, d_u, d_state);
             }
             for (int ev = 0; ev < nbatch && !persistent; ++ev) {
                 select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, 0.0, d_gsum, d_tsum, d_prob, d_type,
@@ -1094,10 +1124,25 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                 tile_sum_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(M, d_prob, d_aff, d_tsum);
                 group_sum_aff_kernel<<<n_aff, KMCF_BLOCK, 0, st>>>(d_aff, nb, d_tsum, d_gsum);
             }
-            if (hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(h_log.data(), d_evlog, 3 * nbatch * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(h_tot.data(), d_totlog, 2 * nbatch * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+            if (pin_ok) {
+                if (hipGetLastError() != hipSuccess) { fail(KMCF_ERR_HIP); break; }
+                const int number = w->batch_number;
+                const auto t_poll = std::chrono::steady_clock::now();
+                int spins = 0;
+                bool synced = false;
+                while (__atomic_load_n(const_cast<const int *>(&p_state->seq), __ATOMIC_ACQUIRE) != number) {
+                    if ((++spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() > 10e-3) {
+                        if (hipStreamSynchronize(st) != hipSuccess) rc = KMCF_ERR_HIP;     // (then the number is there, or the kernel failed)
+                        synced = true;
+                        break;
+                    }
+                }
+                if (rc != KMCF_OK || (synced && p_state->seq != number)) { fail(KMCF_ERR_HIP); break; }
+                hs.done = p_state->done; hs.n_exec = p_state->n_exec;
+            } else if (hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipMemcpyAsync(h_log, d_evlog, 3 * nbatch * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipMemcpyAsync(h_tot, d_totlog, 2 * nbatch * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipStreamSynchronize(st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
             const int n = hs.n_exec;
             for (int e = 0; e < n; ++e)
                 if (h_event_log) for (int q = 0; q < 3; ++q) h_event_log[3 * (nev + e) + q] = h_log[3 * e + q];

@@ -471,7 +471,7 @@ constexpr int EV_PB = 1024;                                 // threads of the pe
 constexpr int EV_GLDS = 1024;                               // group sums the block keeps in LDS (8.4 M rows; beyond: read from gsum)
 constexpr int EV_BMAX = 512;                                // events per batch
 constexpr int EV_AFF = 2 * 64 + 2;                          // rows an event touches at most (nn <= 64)
-constexpr int EV_TREL = 2048;                               // range of the tile claim mask (tiles above the smallest touched one)
+constexpr int EV_TREL = 2048;                               // range of the tile claim table (tiles above the smallest touched one)
 constexpr int EV_GSLOTS = 16;                               // groups an event may claim on the patched path (a wavefront each)
 constexpr int EV_TP = (EV_AFF + 2 * (EV_PB / 64) - 1) / (2 * (EV_PB / 64));    // tile passes: half a wavefront per claimed tile
 static_assert(EV_AFF <= 255 && EV_RT == 32, "slab ids are bytes, a slab's row mask is one word");
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         }
         __syncthreads();
         EV_TICK(3)
-        // ---- group sums: a wavefront per claimed group, the new tile sums looked up through the claim masks
+        // ---- group sums: a wavefront per claimed group, the new tile sums looked up through the claim table
         if (fastp) {
             if (wv < ngrp) {
                 const long long g = s_grp_of[wv];

@@ -470,10 +470,11 @@ constexpr int EV_RT = 32;
 constexpr int EV_PB = 1024;                                 // threads of the persistent block
 constexpr int EV_GLDS = 1024;                               // group sums the block keeps in LDS (8.4 M rows; beyond: read from gsum)
 constexpr int EV_BMAX = 512;                                // events per batch
-constexpr int EV_AFF = 2 * 64 + 2;                          // rows an event touches at most (nn <= 64)
+constexpr int EV_AFF = 2 * 63 + 2;                          // rows an event touches at most (nn <= 63: the entries of two wavefronts)
 constexpr int EV_TREL = 2048;                               // range of the tile claim table (tiles above the smallest touched one)
 constexpr int EV_GSLOTS = 16;                               // groups an event may claim on the patched path (a wavefront each)
-constexpr int EV_TP = (EV_AFF + 2 * (EV_PB / 64) - 1) / (2 * (EV_PB / 64));    // tile passes: half a wavefront per claimed tile
+constexpr int EV_OWN = 128;                                 // owner lists: two wavefronts of entries
+constexpr int EV_TP = EV_OWN / (2 * (EV_PB / 64));          // tile passes at most: half a wavefront per claimed tile
 static_assert(EV_AFF <= 255 && EV_RT == 32, "slab ids are bytes, a slab's row mask is one word");
 
 // Cross-lane partners through the VALU (DPP, and gfx950's v_permlane16/32_swap) instead of ds_bpermute: a double from
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
     __shared__ unsigned int s_slabmask[EV_AFF];            // per owning entry: rows of its tile whose sum this event changed
     __shared__ double s_slab[EV_AFF][EV_RT];               // ... and their new sums
     __shared__ double s_tnew[EV_AFF];                      // per owning entry: new sum of its tile
+    __shared__ int s_own[EV_OWN], s_ocnt[2];               // the owning entries, listed (two lists: see the claims), and how many
     __shared__ double s_g[EV_GLDS], s_u[EV_BMAX], s_nlog[EV_BMAX];
     const int nn = A.nn, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int NW = EV_PB / 64;
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
 #else
 #define EV_TICK(k)
 #endif
-    if (t < 2) { s_gmask[t] = 0ull; s_ngrp[t] = 0; s_slow[t] = 0; }
+    if (t < 2) { s_gmask[t] = 0ull; s_ngrp[t] = 0; s_slow[t] = 0; s_ocnt[t] = 0; }
     for (int q = t; q < EV_TREL; q += EV_PB) s_tent[q] = -1;
     int my_trel = -1;                                      // the table word this thread's entry claimed in the previous event
     // Held in LDS for the whole batch: the group sums (the top of every selection walk; written through to gsum), the
@@ -728,12 +730,20 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             const int tile = valid ? row / EV_RT : 0;
             const int trel = tile - tmin, grel = tile / EV_GROUP - tmin / EV_GROUP;
             int u = valid ? 3 : 0;
+            bool owner = false;
             if (valid) {
                 if (trel < trel_max) {
                     if (atomicCAS(&s_tent[trel], -1, t) != -1) u &= ~1;
-                    else { s_slabmask[t] = 0u; my_trel = trel; }
+                    else { s_slabmask[t] = 0u; my_trel = trel; owner = true; }
                 } else s_slow[par] = 1;
                 if (grel >= 64) s_slow[par] = 1;
+            }
+            // the owners in a list without gaps (the tile passes below walk it instead of all entries): the first
+            // wavefront's from the bottom of s_own, the second's from the top -- no count has to cross between the two
+            {
+                const unsigned long long ob = __ballot(owner);
+                if (owner) { const int lp = __popcll(ob & ((1ull << lane) - 1ull)); s_own[wv == 0 ? lp : EV_OWN - 1 - lp] = t; }
+                if (lane == 0) s_ocnt[wv] = __popcll(ob);
             }
             const bool gv = valid && grel < 64;
             unsigned long long todo = __ballot(gv);
@@ -763,13 +773,22 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         // ---- requests, second part: the row sums of the claimed tiles (half a wavefront per tile) and the tile sums of the
         // claimed groups (a wavefront per group)
         double tp[EV_TP], gp[4] = {0.0, 0.0, 0.0, 0.0};
+        const int c0 = s_ocnt[0], c1 = s_ocnt[1], c0r = (c0 + 31) & ~31, cr = c0r + ((c1 + 31) & ~31);
+        // owner of half-wavefront h in pass p: index v = 32 p + h into the two owner lists, each padded to whole passes
+        auto owner_of = [&](int v) {
+            if (v < c0r) return v < c0 ? s_own[v] : -1;
+            const int uu = v - c0r;
+            return uu < c1 ? s_own[EV_OWN - 1 - uu] : -1;
+        };
 #pragma unroll
         for (int p = 0; p < EV_TP; ++p) {
-            const int e = p * 2 * NW + 2 * wv + (lane >> 5);
             tp[p] = 0.0;
-            if (fastp && e < n_aff && (s_uniq[e] & 1)) {       // (s_uniq != 0 only for entries with a row)
-                const long long rr = (long long)(s_rows[e] / EV_RT) * EV_RT + (lane & 31);
-                if (rr < A.count) tp[p] = rsum[rr];
+            if (fastp && p * 2 * NW < cr) {                    // (wavefront-uniform: passes past the lists are skipped)
+                const int e = owner_of(p * 2 * NW + 2 * wv + (lane >> 5));
+                if (e >= 0) {
+                    const long long rr = (long long)(s_rows[e] / EV_RT) * EV_RT + (lane & 31);
+                    if (rr < A.count) tp[p] = rsum[rr];
+                }
             }
         }
         if (fastp && wv < ngrp) {
@@ -844,8 +863,9 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         if (fastp) {
 #pragma unroll
             for (int p = 0; p < EV_TP; ++p) {
-                const int e = p * 2 * NW + 2 * wv + (lane >> 5), l5 = lane & 31;
-                const bool on = e < n_aff && (s_uniq[e] & 1);
+                if (p * 2 * NW >= cr) continue;                // (wavefront-uniform)
+                const int e = owner_of(p * 2 * NW + 2 * wv + (lane >> 5)), l5 = lane & 31;
+                const bool on = e >= 0;
                 double val = 0.0;
                 if (on) val = ((s_slabmask[e] >> l5) & 1u) ? s_slab[e][l5] : tp[p];
                 const double v = ev_half_sum(val);
@@ -1049,7 +1069,7 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         // exactly as by the reference (two draws per executed event); a foreign callback cannot be rewound,
         // so it gets batches of one.
         // persistent batch kernel (default; KMCF_EVENTS_PERSISTENT=0: three launches per event) with its row-aligned sums
-        const bool persistent = !(getenv("KMCF_EVENTS_PERSISTENT") && atoi(getenv("KMCF_EVENTS_PERSISTENT")) == 0) && nn <= 64;
+        const bool persistent = !(getenv("KMCF_EVENTS_PERSISTENT") && atoi(getenv("KMCF_EVENTS_PERSISTENT")) == 0) && nn <= 63;
         const long long n_tiles2 = ((long long)count + EV_RT - 1) / EV_RT, n_groups2 = (n_tiles2 + EV_GROUP - 1) / EV_GROUP;
         if (persistent) {
             if (!w->d_rsum &&

@@ -472,7 +472,6 @@ constexpr int EV_GLDS = 1024;                               // group sums the bl
 constexpr int EV_BMAX = 512;                                // events per batch
 constexpr int EV_AFF = 2 * 63 + 2;                          // rows an event touches at most (nn <= 63: the entries of two wavefronts)
 constexpr int EV_TREL = 2048;                               // range of the tile claim table (tiles above the smallest touched one)
-constexpr int EV_GSLOTS = 16;                               // groups an event may claim on the patched path (a wavefront each)
 constexpr int EV_OWN = 128;                                 // owner lists: two wavefronts of entries
 constexpr int EV_TP = EV_OWN / (2 * (EV_PB / 64));          // tile passes at most: half a wavefront per claimed tile
 static_assert(EV_AFF <= 255 && EV_RT == 32, "slab ids are bytes, a slab's row mask is one word");
@@ -594,8 +593,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
     // wavefront-local vote, then one atomic per distinct group
     __shared__ int s_tent[EV_TREL];
     __shared__ unsigned long long s_gmask[2];              // (two sets used alternately: set ev & 1 is cleared while event ev + 1 runs)
-    __shared__ int s_ngrp[2], s_slow[2];                   // claimed groups; 1: a touched tile or group is out of the claim range
-    __shared__ int s_grp_of[EV_GSLOTS];
+    __shared__ int s_slow[2];                              // 1: a touched tile or group is out of the claim range
     __shared__ unsigned int s_slabmask[EV_AFF];            // per owning entry: rows of its tile whose sum this event changed
     __shared__ double s_slab[EV_AFF][EV_RT];               // ... and their new sums
     __shared__ double s_tnew[EV_AFF];                      // per owning entry: new sum of its tile
@@ -610,7 +608,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
 #else
 #define EV_TICK(k)
 #endif
-    if (t < 2) { s_gmask[t] = 0ull; s_ngrp[t] = 0; s_slow[t] = 0; s_ocnt[t] = 0; }
+    if (t < 2) { s_gmask[t] = 0ull; s_slow[t] = 0; s_ocnt[t] = 0; }
     for (int q = t; q < EV_TREL; q += EV_PB) s_tent[q] = -1;
     int my_trel = -1;                                      // the table word this thread's entry claimed in the previous event
     // Held in LDS for the whole batch: the group sums (the top of every selection walk; written through to gsum), the
@@ -701,7 +699,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             if (t == 0) s_min[1] = mj;
         }
         if (t == 64) { s_rows[2 * nn] = i_del; s_rows[2 * nn + 1] = j_del; rsum[i_del] = 0.0; rsum[j_del] = 0.0; }
-        if (t == EV_PB - 1) { s_gmask[par ^ 1] = 0ull; s_ngrp[par ^ 1] = 0; s_slow[par ^ 1] = 0; }
+        if (t == EV_PB - 1) { s_gmask[par ^ 1] = 0ull; s_slow[par ^ 1] = 0; }
         if (my_trel >= 0) { s_tent[my_trel] = -1; my_trel = -1; }   // (last read before the previous event's final barrier)
         __syncthreads();
         EV_TICK(1)
@@ -745,23 +743,20 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
                 if (owner) { const int lp = __popcll(ob & ((1ull << lane) - 1ull)); s_own[wv == 0 ? lp : EV_OWN - 1 - lp] = t; }
                 if (lane == 0) s_ocnt[wv] = __popcll(ob);
             }
-            const bool gv = valid && grel < 64;
-            unsigned long long todo = __ballot(gv);
-            bool first = false;
-            while (todo) {
-                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                const int gl = __builtin_amdgcn_readlane(grel, leader);
-                if (lane == leader) first = true;
-                todo &= ~__ballot(gv && grel == gl);
-            }
-            if (gv && !first) u &= ~2;
-            if (first) {
-                if ((atomicOr(&s_gmask[par], 1ull << grel) >> grel) & 1ull) u &= ~2;
-                else {
-                    const int gslot = atomicAdd(&s_ngrp[par], 1);
-                    if (gslot < EV_GSLOTS) s_grp_of[gslot] = tile / EV_GROUP;
-                    else s_slow[par] = 1;
-                }
+            // groups: a bit per touched group above the smallest touched row's, OR-ed over the wavefront through the VALU,
+            // one atomic per wavefront; the group phase walks the set bits (entries whose group is out of the mask's
+            // range keep bit 1 of u and re-add their group themselves on the out-of-range path)
+            {
+                const bool gv = valid && grel < 64;
+                int glo = gv && grel < 32 ? 1 << grel : 0, ghi = gv && grel >= 32 ? 1 << (grel - 32) : 0;
+                glo |= ev_partner_i<32>(glo); ghi |= ev_partner_i<32>(ghi);
+                glo |= ev_partner_i<16>(glo); ghi |= ev_partner_i<16>(ghi);
+                glo |= ev_partner_i<8>(glo); ghi |= ev_partner_i<8>(ghi);
+                glo |= ev_partner_i<4>(glo); ghi |= ev_partner_i<4>(ghi);
+                glo |= ev_partner_i<2>(glo); ghi |= ev_partner_i<2>(ghi);
+                glo |= ev_partner_i<1>(glo); ghi |= ev_partner_i<1>(ghi);
+                if (lane == 0 && (glo | ghi)) atomicOr(&s_gmask[par], ((unsigned long long)(unsigned int)ghi << 32) | (unsigned int)glo);
+                if (gv) u &= ~2;
             }
             if (t < n_aff) s_uniq[t] = u;
         }
@@ -769,7 +764,14 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         __syncthreads();
         EV_TICK(2)
         const bool fastp = s_slow[par] == 0;
-        const int ngrp = s_ngrp[par];
+        // the touched groups: the set bits of the mask, the k-th for wavefront k (then k + 16, ...: those are read again)
+        const unsigned long long gmask = s_gmask[par];
+        const int ngrp = __popcll(gmask), gbase = tmin / EV_GROUP;
+        auto group_of = [&](int k) {                           // k < ngrp, wavefront-uniform
+            unsigned long long mm = gmask;
+            for (int q = 0; q < k; ++q) mm &= mm - 1;
+            return (long long)gbase + (__ffsll((long long)mm) - 1);
+        };
         // ---- requests, second part: the row sums of the claimed tiles (half a wavefront per tile) and the tile sums of the
         // claimed groups (a wavefront per group)
         double tp[EV_TP], gp[4] = {0.0, 0.0, 0.0, 0.0};
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             }
         }
         if (fastp && wv < ngrp) {
-            const long long t0 = (long long)s_grp_of[wv] * EV_GROUP + 4 * lane;
+            const long long t0 = group_of(wv) * EV_GROUP + 4 * lane;
 #pragma unroll
             for (int k = 0; k < 4; ++k) gp[k] = t0 + k < A.n_tiles ? tsum[t0 + k] : 0.0;
         }
@@ -885,8 +887,13 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         EV_TICK(3)
         // ---- group sums: a wavefront per claimed group, the new tile sums looked up through the claim table
         if (fastp) {
+            for (int k = wv + NW; k < ngrp; k += NW) {         // (more than 16 touched groups: the tile sums are in memory by now)
+                const long long g = group_of(k);
+                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
+            }
             if (wv < ngrp) {
-                const long long g = s_grp_of[wv];
+                const long long g = group_of(wv);
                 double s = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -898,7 +905,12 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
                 if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
             }
         } else {
-            for (int e = wv; e < n_aff; e += NW) {
+            for (int k = wv; k < ngrp; k += NW) {              // the groups in the mask's range ...
+                const long long g = group_of(k);
+                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
+            }
+            for (int e = wv; e < n_aff; e += NW) {             // ... and, entry by entry, those beyond it
                 const int row = s_rows[e];
                 if (row < 0 || !(s_uniq[e] & 2)) continue;        // wavefront-uniform
                 const long long g = (row / EV_RT) / EV_GROUP;

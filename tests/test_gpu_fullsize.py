@@ -148,6 +148,37 @@ def test_full_size_event_step_bookkeeping(full, km):
     assert rng.getRandomNumber() == probe.getRandomNumber()                          # two draws per event
 
 
+def test_full_size_event_paths_agree(full, km, monkeypatch):
+    """The persistent batch kernel (row-aligned sums, changed sums patched through LDS, hundreds of groups and tens of
+    thousands of tiles here -- the 5 nm tests have one group) against the three-launch path (slot-aligned sums, every
+    touched tile re-added from memory): the same 300 events, residence times to rounding, the same final state."""
+    S, d, buf, comm, t = full["S"], full["d"], full["buf"], full["comm"], full["torch"]
+    layers = km.structure.LAYERS
+    xs = np.clip(d["xyz"][:, 0], layers[0]["start_x"], layers[-1]["end_x"])
+    lay = t.as_tensor(S.site_layers(xs, layers), device="cuda")
+    el0, ch0 = buf.site_element.clone(), buf.site_charge.clone()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KMCF_EVENTS_PERSISTENT", mode)
+        buf.site_element.copy_(el0)
+        buf.site_charge.copy_(ch0)
+        rng = S.RandomNumberGenerator(11)
+        tev, nev, log = S.execute_kmc_step_mpi(comm, d["N"], comm.counts_events, comm.displs_events, 52, buf.neigh_idx, lay,
+                                               77.0, 10e13, d["sigma"], d["k"], buf.site_x, buf.site_y, buf.site_z,
+                                               buf.site_potential_charge, buf.site_element, buf.site_charge, rng, layers,
+                                               max_events=300, return_log=True)
+        out[mode] = (tev, nev, log.copy(), buf.site_element.cpu().numpy().copy(), buf.site_charge.cpu().numpy().copy())
+    monkeypatch.delenv("KMCF_EVENTS_PERSISTENT", raising=False)
+    a, b = out["1"], out["0"]
+    assert a[1] == b[1] == 300
+    np.testing.assert_array_equal(a[2], b[2])
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+    np.testing.assert_array_equal(a[3], b[3])
+    np.testing.assert_array_equal(a[4], b[4])
+    buf.site_element.copy_(el0)
+    buf.site_charge.copy_(ch0)
+
+
 def test_full_size_current_and_heat(full, km):
     """BASELINE config 3 at full size: conduction-band edge, T assembly (1 046 913-row neighbour matrix whose two
     virtual-node rows hold 19 200 entries each: the long-row kernel; tunnel sub-block over the 19 697 vacancies:

@@ -306,7 +306,11 @@ int cg_chunk_check(kmcf_comm *c, const kmcf_scalars *S, hipStream_t st, bool *do
         *done = c->h_pinned[0] != 0;
         return KMCF_OK;
     }
+    if (c->mark_seq == 0x7fffffff) c->mark_seq = 0;
     const int number = ++c->mark_seq;
+    // the word the host polls must differ from the number waited for BEFORE the kernel that writes it is enqueued
+    // (pinned blocks are recycled by the runtime; nothing else writes this word between checks)
+    __atomic_store_n(c->h_pinned + 2, 0, __ATOMIC_RELEASE);
     cg_mark_kernel<<<1, 64, 0, st>>>(S, c->h_pinned, number);
     KMCF_HIP(hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();

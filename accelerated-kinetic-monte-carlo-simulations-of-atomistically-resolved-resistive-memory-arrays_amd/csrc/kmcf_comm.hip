@@ -28,6 +28,7 @@ struct rccl_api {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 rccl_api g_rccl;
@@ -52,6 +53,7 @@ int load_rccl()
     KMCF_SYM(Recv, "ncclRecv");
     KMCF_SYM(GroupStart, "ncclGroupStart");
     KMCF_SYM(GroupEnd, "ncclGroupEnd");
+    KMCF_SYM(CommCount, "ncclCommCount");
     KMCF_SYM(GetErrorString, "ncclGetErrorString");
 #undef KMCF_SYM
     g_rccl.handle = h;
@@ -133,6 +135,11 @@ extern "C" int kmcf_comm_create(kmcf_comm **out, int device, int nranks, int ran
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), 1024 * sizeof(double)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 16 * sizeof(int), hipHostMallocDefault));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_scal), sizeof(kmcf_scalars), hipHostMallocDefault));
+    // the host polls h_pinned[2] for the number of a chunk check (cg_chunk_check): a recycled pinned block must not
+    // already hold the first number that will be waited for
+    memset(c->h_pinned, 0, 16 * sizeof(int));
+    memset(c->h_scal, 0, sizeof(kmcf_scalars));
+    c->mark_seq = 0;
     c->connected = (nranks == 1);
     *out = c;
     return KMCF_OK;
@@ -477,6 +484,13 @@ extern "C" const char *kmcf_comm_transport(const kmcf_comm *c)
     if (!c || c->nranks == 1) return "single";
     if (c->p2p_active) return c->group ? "p2p (in-process group)" : (c->nccl ? "p2p (bootstrapped over rccl)" : "p2p");
     return c->group ? "loopback" : "rccl";
+}
+
+extern "C" int kmcf_comm_rccl_ranks(const kmcf_comm *c)
+{
+    if (!c || !c->nccl_red || !g_rccl.CommCount) return 0;
+    int n = 0;
+    return g_rccl.CommCount(static_cast<ncclComm_t>(c->nccl_red), &n) == ncclSuccess ? n : -1;
 }
 
 // Sum `count` doubles in place over all ranks, on the compute stream, device resident.

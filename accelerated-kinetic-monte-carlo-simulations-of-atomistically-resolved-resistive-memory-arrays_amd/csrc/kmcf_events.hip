@@ -17,6 +17,7 @@
 // returned time).  Ranks own contiguous site ranges; the partial totals are all-gathered and the rank
 // whose range holds the drawn number selects (MPI_Allgather + MPI_Bcast in the reference, :423-470).
 #include <climits>
+#include <cstring>
 #include <chrono>
 #include <cmath>
 #include <random>
@@ -1115,7 +1116,10 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
         const bool pinned = persistent && !(getenv("KMCF_EVENTS_PINNED") && atoi(getenv("KMCF_EVENTS_PINNED")) == 0);
         constexpr size_t PIN_LOG = 64, PIN_TOT = PIN_LOG + 3 * EV_BMAX * sizeof(int), PIN_U = PIN_TOT + 2 * EV_BMAX * sizeof(double),
                          PIN_END = PIN_U + 2 * EV_BMAX * sizeof(double);
-        if (pinned && !w->h_pin && hipHostMalloc(reinterpret_cast<void **>(&w->h_pin), PIN_END, hipHostMallocDefault) != hipSuccess) fail(KMCF_ERR_HIP);
+        if (pinned && !w->h_pin) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&w->h_pin), PIN_END, hipHostMallocDefault) != hipSuccess) fail(KMCF_ERR_HIP);
+            else { memset(w->h_pin, 0, PIN_END); w->batch_number = 0; }      // the polled number (state.seq) starts below the first one waited for
+        }
         std::vector<double> h_u_v(2 * BMAX), h_tot_v(2 * BMAX);
         std::vector<int> h_log_v(3 * BMAX);
         const bool pin_ok = pinned && w->h_pin;
@@ -1135,7 +1139,8 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
             }
             event_batch_state hs = {0, 0, 0, 0};
             if (pin_ok) {
-                p_state->done = 0; p_state->n_exec = 0;
+                if (w->batch_number == 0x7fffffff) w->batch_number = 0;
+                p_state->done = 0; p_state->n_exec = 0; p_state->seq = 0;      // never equal to the number about to be waited for
             } else if (hipMemcpyAsync(d_u, h_u, 2 * nbatch * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
                        hipMemsetAsync(d_state, 0, sizeof(event_batch_state), st) != hipSuccess) { fail(KMCF_ERR_HIP); break; }
             if (persistent) {

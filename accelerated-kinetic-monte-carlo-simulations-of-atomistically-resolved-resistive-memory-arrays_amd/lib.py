@@ -74,6 +74,7 @@ SIGNATURES = {
     "kmcf_comm_p2p_import": (C.c_int, [_P, _P]),
     "kmcf_comm_transport": (C.c_char_p, [_P]),
     "kmcf_comm_select_transport": (C.c_int, [_P, C.c_int]),
+    "kmcf_comm_rccl_ranks": (C.c_int, [_P]),
     "kmcf_partition": (C.c_int, [C.c_int, C.c_int, _IP, _IP]),
     "kmcf_matrix_create_csr": (C.c_int, [_P, C.c_int, _IP, _IP, _IP, _IP, _DP, C.POINTER(_P)]),
     "kmcf_matrix_destroy": (C.c_int, [_P]),

@@ -107,6 +107,9 @@ class KMC_comm:
     def transport(self):
         return self.lib.kmcf_comm_transport(self.handle).decode()
 
+    def rccl_ranks(self):
+        return int(self.lib.kmcf_comm_rccl_ranks(self.handle))
+
     def select_transport(self, use_p2p):
         _L.check(self.lib.kmcf_comm_select_transport(self.handle, 1 if use_p2p else 0), "kmcf_comm_select_transport")
 

@@ -23,6 +23,56 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def self_launch(args):
+    """Parent of a multi-rank run started as ONE command.  Never initialises a GPU: a process that has done so must
+    not be replaced or forked into rank processes on this pool, so the ranks are children of a process that only
+    waits.  Returns the exit code to leave with."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL and the peer-to-peer windows need it here
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+
+    def relay():
+        for line in child.stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the %d ranks did not finish within %.0f s; ending their process group\n"
+                         % (args.gpus, args.launch_timeout))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)          # the group this call created (start_new_session), nothing else
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    t.join(timeout=5)
+    if rc == 0 and not any(l.lstrip().startswith("{") and '"metric"' in l for l in lines):
+        sys.stderr.write("bench.py: the ranks exited 0 without printing the result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,7 +89,16 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "p2p", "p2p-only"],
                     help="multi-rank data path: auto = peer-to-peer windows if they come up, else RCCL; p2p-only = no RCCL at "
                          "all (rehearsal of N ranks on fewer GPUs, where RCCL refuses to run)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 without WORLD_SIZE: seconds the self-launched ranks may take before they are ended")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as one plain command: this process becomes the launcher.  It touches no GPU
+        # (no torch import, no library load), starts the N ranks as a CHILD process group through
+        # torch.distributed.run -- the protocol of the reference's own benchmark is one MPI rank per GPU,
+        # dist_iterative_test/main_test_cg.cpp:94-118 -- relays rank 0's JSON line and exits with the child's code.
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
@@ -57,6 +116,9 @@ def main():
         # rehearsal: several ranks share a GPU; their chip-filling grids take a share each (kmcf_internal.hpp)
         os.environ.setdefault("KMCF_DEVICE_SHARE", str((world + torch.cuda.device_count() - 1) // max(torch.cuda.device_count(), 1)))
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible, %d ranks); --transport p2p-only rehearses more ranks than GPUs"
+                         % (rank, torch.cuda.device_count(), world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         # gloo only carries the 256-byte RCCL bootstrap id, barriers and the max-over-ranks
@@ -152,16 +214,31 @@ def main():
     if world > 1 and comm.transport().startswith("p2p"):
         has_rccl = comm.transport() == "p2p (bootstrapped over rccl)"
         transports = {}
+        p2p_failed = False
         for name in (["rccl"] if has_rccl else []) + list(P2P_MODES):
+            if name != "rccl" and p2p_failed:
+                # the peer-to-peer error word is sticky and shared by the three protocol modes: once a bounded wait has
+                # expired on ANY rank every later mode would only time out again (10 s each), so none is tried
+                transports[name] = {"error": "not tried: an earlier peer-to-peer trial failed"}
+                continue
+            err = None
             try:
                 if has_rccl:
                     comm.select_transport(0 if name == "rccl" else 1)
                 set_mode(name)
                 t_trial, st_trial = timed_solve(min(args.steps, 20), 3)
+            except km.lib.KmcfError as e:
+                err = str(e)[:200]
+            # the ranks must agree on what happened (a KmcfError is caught per rank)
+            bad = torch.tensor([1 if err else 0])
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                transports[name] = {"error": err or "failed on another rank"}
+                if name != "rccl":
+                    p2p_failed = True
+            else:
                 transports[name] = {"trial_ms_per_step": round(t_trial * 1e3 / min(args.steps, 20), 5),
                                     "trial_rz": st_trial["rz"]}
-            except km.lib.KmcfError as e:
-                transports[name] = {"error": str(e)[:200]}
         # every candidate runs the same recurrence (the dots differ only in the order the ranks' partial sums are
         # added, and only on RCCL): a residual that disagrees beyond rounding means an exchange delivered wrong data
         ref = next((v["trial_rz"] for v in transports.values() if "trial_rz" in v), None)
@@ -170,9 +247,10 @@ def main():
                 transports[name] = {"error": "residual after the trial solve differs: %r vs %r" % (v["trial_rz"], ref)}
         ok = {k: v["trial_ms_per_step"] for k, v in transports.items() if "trial_ms_per_step" in v}
         names = list(transports)
-        best = min(ok, key=ok.get) if ok else names[0]
-        pick = torch.tensor([names.index(best)])
+        pick = torch.tensor([names.index(min(ok, key=ok.get)) if ok else -1])
         dist.broadcast(pick, src=0)                 # rank 0 decides
+        if int(pick.item()) < 0:
+            raise SystemExit("bench.py: no transport passed its trial solve: %s" % json.dumps(transports))
         best = names[int(pick.item())]
         if has_rccl:
             comm.select_transport(0 if best == "rccl" else 1)
@@ -330,7 +408,9 @@ def main():
     diag = None
     if world > 1:
         reps = 200
-        diag = {"transport_used": comm.transport(), "cg_variant": os.environ.get("KMCF_CG_VARIANT", "cg1r")}
+        diag = {"transport_used": comm.transport(), "cg_variant": os.environ.get("KMCF_CG_VARIANT", "cg1r"),
+                "rccl_ranks": comm.rccl_ranks(), "devices_visible": torch.cuda.device_count(),
+                "ranks_per_device": int(os.environ.get("KMCF_DEVICE_SHARE", "1"))}
         if transports is not None:
             diag["transports"] = transports
         used_p2p = comm.transport().startswith("p2p")

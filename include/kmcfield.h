@@ -84,6 +84,10 @@ const char *kmcf_comm_transport(const kmcf_comm *c);   /* "single", "loopback", 
  * them; collective (every rank, same value), between solves.  Matrices built while the peer-to-peer transport was
  * active work on either. */
 int kmcf_comm_select_transport(kmcf_comm *c, int use_p2p);
+/* Ranks the RCCL communicator itself reports (ncclCommCount): 0 when no RCCL communicator is connected (one rank,
+ * in-process groups, groups bootstrapped through the host program), -1 on an RCCL error.  The reference's benchmark
+ * prints MPI_Comm_size the same way (dist_iterative_test/main_test_cg.cpp:94-118). */
+int kmcf_comm_rccl_ranks(const kmcf_comm *c);
 int kmcf_comm_sync(kmcf_comm *c);            /* wait for the solver streams      */
 void *kmcf_comm_stream(kmcf_comm *c);        /* hipStream_t of the compute stream */
 /* Declares the hipStream_t the caller queues its own device work on (NULL = legacy null

@@ -333,6 +333,7 @@ int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *s
     KMCF_HIP(hipStreamSynchronize(c->stream));
     if (c->nranks > 1 || c->force_collectives) KMCF_HIP(hipStreamSynchronize(c->comm_stream));
     KMCF_TRY(kmcf_p2p_check(c));
+    KMCF_TRY(kmcf_cgr_check(m));
     const kmcf_scalars &hS = *c->h_scal;
     if (stats) {
         stats->iterations = hS.iters;
@@ -806,11 +807,26 @@ static int pcg_workspace_flags(kmcf_matrix *m, bool precond, double tol, int max
     return rc;
 }
 
+// The single-reduction recurrence as ONE register-resident launch (kmcf_cgr.hip), for matrices whose tiles are all
+// resident at once.  Workspace in, workspace out, scalars in d_S -- like the loops.
+static int pcg_resident(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
+{
+    kmcf_comm *c = m->comm;
+    hipStream_t st = c->stream;
+    KMCF_HIP(hipEventRecord(c->ev_t0, st));
+    KMCF_TRY(kmcf_cgr_solve(m, precond, tol, max_it, fixed_iters));
+    KMCF_HIP(hipEventRecord(c->ev_t1, st));
+    if (flags & 2) return KMCF_OK;                 // the caller's output kernel writes the scalars to the host
+    KMCF_HIP(hipMemcpyAsync(c->h_scal, m->d_S, sizeof(kmcf_scalars), hipMemcpyDeviceToHost, st));
+    return pcg_collect(m, tol * tol, 0, stats);
+}
+
 static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
 {
     // classic = the reference's recurrence and operation order (default for one rank);
     // cg1r = single-reduction variant (default for multi-rank groups)
     if (kmcf_cg_single_reduction(m)) {
+        if (kmcf_cgr_usable(m) && (fixed_iters > 0 || max_it > 0)) return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags);
         if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
         return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }

@@ -1,0 +1,596 @@
+// Register-resident Jacobi-PCG: a whole solve in ONE launch, for matrices small enough that every 256-row tile of the
+// row-per-lane layout (kmcf_spmv.hip, spmv_sell_kernel) can have its own 256 lanes resident at the same time -- a rank's
+// share of the 40 nm crossbar from four ranks on (<= 2048 tiles = 524 288 rows per GPU), the whole 5 nm device.
+// Replaces, for those matrices, the loop of iterative_solver::conjugate_gradient_jacobi
+// (dist_iterative/dist_conjugate_gradient.cpp:149-276) that kmcf_cg.hip runs as 2-3 kernels per iteration.
+//
+// Why.  A rank's eighth of the 40 nm matrix iterates in 14.7 us with two kernels per iteration, of which ~9 us are
+// not bytes but kernel boundaries and the chain of dependent memory round trips every short kernel starts with
+// ("scaling expectation").  MI355X has 128 MB of vector registers and 40 MB of LDS: the rank's matrix
+// stream (2 B per entry), its five CG vectors and the tile's window map all FIT in the registers of the lanes that
+// own the rows.  So nothing is re-read: lane t of tile c keeps row r0 + t's x, r, p, s, 1/diag, diagonal, its slice
+// of the entry stream and its window columns in registers for the whole solve, and per iteration only two things
+// cross block boundaries:
+//   (1) z of the neighbouring tiles (the tile's window), and
+//   (2) the iteration's dot products (single-reduction recurrence of Chronopoulos & Gear, as pcg1_loop: one reduction
+//       point per iteration).
+// Both go AROUND the L2s (which are per XCD and not coherent with each other inside a kernel) with agent-scope
+// accesses, and both carry their own sequence number, so that no flag, fence or wait-for-stores sits between
+// writing a value and somebody else using it ("LL" encoding, as RCCL's low-latency protocol does over xGMI):
+//   a double travels as two 8-byte words, {low 32 bits | seq << 32} and {high 32 bits | seq << 32}; a reader polls
+//   the two words until both carry the sequence number it expects.  8-byte aligned accesses are single-copy atomic,
+//   so a word is either the old or the new one.  Buffers are double-buffered by the parity of the sequence number;
+//   the reduction in every iteration keeps any block from running two versions ahead of a reader.
+// Reduction: every block publishes its sums in a 128-byte line of its own; the leader of each group of g1 blocks adds
+// its group (one lane per block, wavefront butterfly) and publishes the group's sums; every block adds the group sums
+// (one lane per group, butterfly).  No read-modify-write on a shared word (256 same-address atomics cost ~10 us,
+// tools/lab/gridbar_lab.hip), two memory hops, the same numbers in the same order in every block -- and in the oracle
+// (oracle/kmcf_oracle_order.c: orc_pcg1_resident_order), which must agree bit for bit.
+// Measured before it was written: tools/lab/resident_lab.hip (881 tiles: 6.7 us per iteration with one block per CU).
+//
+// Every wait is bounded by the wall clock (KMCF_CGR_TIMEOUT_MS, default 4000): expiry sets an error word, every other
+// wait returns at once, the host returns KMCF_ERR_STATE.  All blocks of the launch must be resident together: the
+// grid is checked against the occupancy of the kernel (times the CUs, divided by KMCF_DEVICE_SHARE).
+#include <cstring>
+
+#include "kmcf_p2p_dev.hpp"
+
+namespace {
+
+typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries of the stream (kmcf_spmv.hip)
+constexpr int CGR_W = 1 << KMCF_SLOT_BITS;     // window slots per dictionary value
+constexpr int CGR_WQ = CGR_W / KMCF_BLOCK - 1; // outside columns per lane
+constexpr int CGR_LINE = 16;                   // 8-byte words per 128-byte line
+constexpr int CGR_NV = 3;                      // sums per reduction (gamma, delta, b.b)
+
+}  // namespace
+
+struct kmcf_cgr {
+    int tpb = 0, nblocks = 0, g1 = 0, ngroups = 0;
+    u64 *d_zll = nullptr;          // [2][2 * (n_loc + n_halo)]: LL words of z, by parity of the sequence number
+    u64 *d_slot = nullptr;         // [2][nblocks][CGR_LINE]
+    u64 *d_gslot = nullptr;        // [2][ngroups][CGR_LINE]
+    unsigned int *d_seq = nullptr; // last sequence number the previous solve used (the kernel reads and advances it)
+    int *d_err = nullptr, *h_err = nullptr;
+    unsigned long long seq_bound = 1;   // host's upper bound of *d_seq (wrap protection)
+    size_t zwords = 0;
+};
+
+namespace {
+
+struct cgr_args {
+    int n_tiles, nblocks, g1, ngroups;
+    const int4 *tile4;
+    const int2 *swave;
+    const int *wcol;
+    const sell_pair *stream;
+    const double *dict, *diagv;
+    double *r, *x;
+    const double *dinv;              // nullptr: unpreconditioned
+    kmcf_scalars *S;
+    u64 *zll;
+    long long zwords;                // words per parity buffer
+    u64 *slot, *gslot;
+    unsigned int *seq;
+    int *d_err, *h_err;
+    long long timeout;
+    int limit, check_tol;
+    double tol2;
+};
+
+__device__ __forceinline__ u64 cgr_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cgr_st(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void ll_store(u64 *p, double v, unsigned int seq)
+{
+    const u64 b = (u64)__double_as_longlong(v), s = (u64)seq << 32;
+    cgr_st(p, (b & 0xffffffffull) | s);
+    cgr_st(p + 1, (b >> 32) | s);
+}
+__device__ __forceinline__ bool ll_try(const u64 *p, unsigned int seq, double &v)
+{
+    const u64 a = cgr_ld(p), b = cgr_ld(p + 1);
+    if ((unsigned int)(a >> 32) != seq || (unsigned int)(b >> 32) != seq) return false;
+    v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+    return true;
+}
+
+// The same two words as ONE 16-byte access through a buffer descriptor with the sc1 bit (aux = 16): consecutive lanes
+// that read consecutive values are merged by the texture path into one request per run (8-byte accesses of a 16-byte
+// pitch are not: one request per lane and word; the z gather of a rank's eighth is bound by that request count).
+// Tear-safe without any assumption about 16-byte atomicity: each 8-byte half carries the sequence number.
+typedef unsigned int cgr_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_store16(__amdgpu_buffer_rsrc_t rs, unsigned int byte_off, double v, unsigned int seq)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const cgr_u4 d = {(unsigned int)b, seq, (unsigned int)(b >> 32), seq};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ bool ll_try16(__amdgpu_buffer_rsrc_t rs, unsigned int byte_off, unsigned int seq, double &v)
+{
+    const cgr_u4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    if (d.y != seq || d.w != seq) return false;
+    v = __longlong_as_double((long long)((u64)d.x | ((u64)d.z << 32)));
+    return true;
+}
+
+struct cgr_wait {
+    long long t0, timeout;
+    int *d_err, *h_err;
+    int spins;
+    bool failed;
+    // called after an unsuccessful poll: true = give up (this wait or somebody else's has expired)
+    __device__ __forceinline__ bool give_up(int code)
+    {
+        if ((++spins & 15) == 0) {
+            if (__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { failed = true; return true; }
+            if (wall_clock64() - t0 > timeout) {
+                __hip_atomic_store(d_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                failed = true;
+                return true;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        return false;
+    }
+};
+
+// One solve.  Block b owns tiles b TPB ... b TPB + TPB - 1 (256 threads each); blocks of one launch are all resident.
+template <int NQ, int ND, int TPB>
+__global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
+{
+    extern __shared__ double cgr_lds[];
+    double *red = cgr_lds + (size_t)TPB * ND * CGR_W;      // [CGR_NV][16] wavefront sums
+    double *bc = red + CGR_NV * 16;                        // [CGR_NV] reduced sums, for every thread; flat reduction: [CGR_NV][4] wave sums
+    const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), gw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *xs = cgr_lds + (size_t)sub * ND * CGR_W;
+    const int c = blockIdx.x * TPB + sub;
+    const bool active = c < A.n_tiles;
+    const int4 d = active ? A.tile4[c] : make_int4(0, 0, 0, 0);          // (first row, rows, first window slot, outside columns)
+    const int2 sw = active ? A.swave[c * 4 + wv] : make_int2(0, 0);      // (first 8-byte group of the wave's stream, steps)
+    const bool has_row = t < d.y;
+    const int row = d.x + t;
+    int wc[CGR_WQ];
+#pragma unroll
+    for (int q = 0; q < CGR_WQ; ++q) wc[q] = (q * KMCF_BLOCK + t < d.w) ? A.wcol[d.z + q * KMCF_BLOCK + t] : -1;
+    sell_pair pk[NQ];
+    {
+        const sell_pair *sp = A.stream + sw.x + lane;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pk[q] = q < sw.y ? sp[q * 64] : sell_pair{0u, 0u};
+    }
+    double dv[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dv[k] = A.dict[k];
+    const double dg = has_row ? A.diagv[row] : 0.0;
+    const double di = has_row ? (A.dinv ? A.dinv[row] : 1.0) : 0.0;
+    const double b_i = has_row ? A.r[row] : 0.0;
+    double x = has_row ? A.x[row] : 0.0;
+    unsigned int seq = *A.seq;                   // (read by every block before block 0 overwrites it at the very end)
+    cgr_wait W{wall_clock64(), A.timeout, A.d_err, A.h_err, 0, false};
+#ifdef KMCF_CGR_PROFILE
+    long long tp_gather = 0, tp_row = 0, tp_red1 = 0, tp_red2 = 0, tp_red3 = 0, tp_mark = 0;
+#define CGR_T0() tp_mark = wall_clock64()
+#define CGR_T(acc) do { const long long n_ = wall_clock64(); acc += n_ - tp_mark; tp_mark = n_; } while (0)
+#else
+#define CGR_T0() do { } while (0)
+#define CGR_T(acc) do { } while (0)
+#endif
+
+    // z (or x0) of this lane's row, version `seq`, to whoever has the row in its window
+    const __amdgpu_buffer_rsrc_t zrs[2] = {__builtin_amdgcn_make_buffer_rsrc(A.zll, 0, (int)(A.zwords * 8), 0x00020000),
+                                           __builtin_amdgcn_make_buffer_rsrc(A.zll + A.zwords, 0, (int)(A.zwords * 8), 0x00020000)};
+    const __amdgpu_buffer_rsrc_t srs[2] = {__builtin_amdgcn_make_buffer_rsrc(A.slot, 0, A.nblocks * 128, 0x00020000),
+                                           __builtin_amdgcn_make_buffer_rsrc(A.slot + (size_t)A.nblocks * CGR_LINE, 0, A.nblocks * 128, 0x00020000)};
+    auto publish = [&](double v) {
+        if (has_row) {
+            if (seq & 1) ll_store16(zrs[1], 16u * (unsigned int)row, v, seq);
+            else ll_store16(zrs[0], 16u * (unsigned int)row, v, seq);
+        }
+    };
+    // y_row = sum of the row's products with version `seq` of the vector whose own entry is `own`
+    auto spmv = [&](double own) -> double {
+        const __amdgpu_buffer_rsrc_t zb = (seq & 1) ? zrs[1] : zrs[0];
+        CGR_T0();
+        double g[CGR_WQ];
+        bool need[CGR_WQ];
+#pragma unroll
+        for (int q = 0; q < CGR_WQ; ++q) { g[q] = 0.0; need[q] = wc[q] >= 0; }
+        while (true) {
+            bool all = true;
+#pragma unroll
+            for (int q = 0; q < CGR_WQ; ++q)
+                if (need[q]) {
+                    if (ll_try16(zb, 16u * (unsigned int)wc[q], seq, g[q])) need[q] = false;
+                    else all = false;
+                }
+            if (all || W.give_up(11)) break;
+            asm volatile("" ::: "memory");                 // (the next pass loads again)
+        }
+        CGR_T(tp_gather);
+#pragma unroll
+        for (int k = 0; k < ND; ++k) xs[k * CGR_W + t] = dv[k] * own;                 // (lanes without a row: own = 0)
+#pragma unroll
+        for (int q = 0; q < CGR_WQ; ++q) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) xs[k * CGR_W + KMCF_BLOCK + q * KMCF_BLOCK + t] = dv[k] * g[q];   // (past the window: 0.0, the padding target)
+        }
+        __syncthreads();
+        const char *base = reinterpret_cast<const char *>(xs);
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q < sw.y) {
+                const sell_pair e = pk[q];
+                const double a0 = *reinterpret_cast<const double *>(base + (e.x & 0xffffu));
+                const double a1 = *reinterpret_cast<const double *>(base + (e.x >> 16));
+                const double a2 = *reinterpret_cast<const double *>(base + (e.y & 0xffffu));
+                const double a3 = *reinterpret_cast<const double *>(base + (e.y >> 16));
+                s += a0; s += a1; s += a2; s += a3;
+            }
+        }
+        s += dg * own;
+        __syncthreads();                                   // (xs is written again by the next product)
+        CGR_T(tp_row);
+        return has_row ? s : 0.0;
+    };
+    // sums over all rows of up to CGR_NV per-lane values, number `rs`; the same value in every thread of every block
+    // (returns false -- in every thread of the block alike -- when a wait of this block has given up)
+    auto reduce = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV], unsigned int rs) -> bool {
+        CGR_T0();
+        v0 = kmcf_wave_sum64(v0); v1 = kmcf_wave_sum64(v1);
+        if (nv > 2) v2 = kmcf_wave_sum64(v2);
+        if (lane == 0) { red[gw] = v0; red[16 + gw] = v1; red[32 + gw] = v2; }
+        __syncthreads();
+        u64 *sl = A.slot + ((size_t)(rs & 1) * A.nblocks + blockIdx.x) * CGR_LINE;
+        if (tid < nv) {                                    // tile sums (w0 + w1) + (w2 + w3), tiles in pairs
+            const double *w = red + 16 * tid;
+            double tsum[TPB];
+#pragma unroll
+            for (int j = 0; j < TPB; ++j) tsum[j] = (w[4 * j] + w[4 * j + 1]) + (w[4 * j + 2] + w[4 * j + 3]);
+            double bsum = tsum[0];
+            if (TPB == 2) bsum = tsum[0] + tsum[1];
+            if (TPB == 4) bsum = (tsum[0] + tsum[1]) + (tsum[2] + tsum[3]);
+            if (A.g1 == 0) ll_store16((rs & 1) ? srs[1] : srs[0], 128u * blockIdx.x + 16u * tid, bsum, rs);
+            else ll_store(sl + 2 * tid, bsum, rs);
+        }
+        CGR_T(tp_red1);
+        if (A.g1 == 0) {
+            // flat (<= 256 blocks): ONE hop -- every block reads every block's line itself, lane l of wave w that of block
+            // 64 w + l; a wave adds its 64 (butterfly), the four wave sums as (w0 + w1) + (w2 + w3)
+            if (gw < 4) {
+                const int q = 64 * gw + lane;
+                const bool mine = q < A.nblocks;
+                const __amdgpu_buffer_rsrc_t sb = (rs & 1) ? srs[1] : srs[0];
+                double g[CGR_NV] = {0.0, 0.0, 0.0};
+                bool need[CGR_NV] = {mine, mine, mine && nv > 2};
+                while (true) {
+                    bool all = true;
+#pragma unroll
+                    for (int i = 0; i < CGR_NV; ++i)
+                        if (need[i]) {
+                            if (ll_try16(sb, 128u * (unsigned int)q + 16u * i, rs, g[i])) need[i] = false;
+                            else all = false;
+                        }
+                    if (all || W.give_up(12)) break;
+                    asm volatile("" ::: "memory");
+                }
+                g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
+                if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);
+                if (lane == 0) { bc[gw] = g[0]; bc[4 + gw] = g[1]; bc[8 + gw] = g[2]; }
+            }
+            const int bad = __syncthreads_or(W.failed ? 1 : 0);
+            CGR_T(tp_red3);
+#pragma unroll
+            for (int i = 0; i < CGR_NV; ++i) out[i] = (bc[4 * i] + bc[4 * i + 1]) + (bc[4 * i + 2] + bc[4 * i + 3]);
+            __syncthreads();
+            return bad == 0;
+        }
+        if (gw == 0 && blockIdx.x % A.g1 == 0) {           // leader of a group: one lane per block of the group
+            const int q = blockIdx.x + lane;
+            const bool mine = lane < A.g1 && q < A.nblocks;
+            const u64 *sq = A.slot + ((size_t)(rs & 1) * A.nblocks + (mine ? q : blockIdx.x)) * CGR_LINE;
+            double g[CGR_NV] = {0.0, 0.0, 0.0};
+            bool need[CGR_NV] = {mine, mine, mine && nv > 2};
+            while (true) {
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < CGR_NV; ++i)
+                    if (need[i]) {
+                        if (ll_try(sq + 2 * i, rs, g[i])) need[i] = false;
+                        else all = false;
+                    }
+                if (all || W.give_up(12)) break;
+            }
+            g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
+            if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);
+            u64 *gs = A.gslot + ((size_t)(rs & 1) * A.ngroups + blockIdx.x / A.g1) * CGR_LINE;
+            if (lane < nv) ll_store(gs + 2 * lane, lane == 0 ? g[0] : (lane == 1 ? g[1] : g[2]), rs);
+            CGR_T(tp_red2);
+        }
+        if (gw == 1) {                                     // every block: one lane per group
+            const bool mine = lane < A.ngroups;
+            const u64 *gq = A.gslot + ((size_t)(rs & 1) * A.ngroups + (mine ? lane : 0)) * CGR_LINE;
+            double g[CGR_NV] = {0.0, 0.0, 0.0};
+            bool need[CGR_NV] = {mine, mine, mine && nv > 2};
+            while (true) {
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < CGR_NV; ++i)
+                    if (need[i]) {
+                        if (ll_try(gq + 2 * i, rs, g[i])) need[i] = false;
+                        else all = false;
+                    }
+                if (all || W.give_up(13)) break;
+            }
+            g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
+            if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);
+            if (lane == 0) { bc[0] = g[0]; bc[1] = g[1]; bc[2] = g[2]; }
+        }
+        const int bad = __syncthreads_or(W.failed ? 1 : 0);
+        CGR_T(tp_red3);
+        out[0] = bc[0]; out[1] = bc[1]; out[2] = bc[2];
+        __syncthreads();                                   // (red / bc are written again by the next reduction)
+        return bad == 0;
+    };
+
+    // ---- r = b - A x0 ; z = r .* dinv ; gamma = (r, z) ; b.b                 (dist_conjugate_gradient.cpp:178-213)
+    ++seq;
+    publish(x);
+    const double ax = spmv(has_row ? x : 0.0);
+    double r = b_i + (-1.0) * ax;
+    double z = r * di;
+    double gp = r * z, bbp = b_i * b_i;
+    double p = 0.0, s = 0.0;
+    ++seq;
+    publish(z);
+    // ---- loop (:217-266 in the single-reduction form, kmcf_cg.hip: cg1_update_kernel)
+    double bb = 0.0, g_old = 0.0, a_old = 0.0, rz_last = 0.0, pAp = 0.0;
+    int iters = 0, done = 0;
+    bool ok = true;
+    for (int k = 1; k <= A.limit; ++k) {
+        const bool first = k == 1;
+        const double w = spmv(has_row ? z : 0.0);
+        double sums[CGR_NV];
+        ok = reduce(first ? 3 : 2, gp, z * w, bbp, sums, seq);
+        if (!ok) break;
+        const double gamma = sums[0], delta = sums[1];
+        if (first) bb = sums[2];
+        const bool go = A.check_tol ? (gamma / bb > A.tol2) : true;
+        rz_last = gamma;
+        if (!go) { done = 1; break; }
+        double beta = 0.0, alpha;
+        if (first) alpha = gamma / delta;
+        else {
+            beta = gamma / g_old;
+            alpha = gamma / (delta - beta * gamma / a_old);
+        }
+        g_old = gamma; a_old = alpha; pAp = delta;
+        ++iters;
+        const double na = -alpha;
+        s = first ? w : w + beta * s;
+        r = r + na * s;
+        const double zn = r * di;
+        ++seq;
+        publish(zn);                 // (on its way before the rest of the update)
+        p = first ? z : z + beta * p;
+        x = x + alpha * p;
+        z = zn;
+        gp = r * z;
+    }
+    if (!done && ok) {               // the loop condition once more after the last iteration (:217, :273): r.z only.  Its number is
+        double sums[CGR_NV];         // the current version's: one above the last reduction's, so the slot parities alternate
+        reduce(2, gp, 0.0, 0.0, sums, seq);
+        rz_last = sums[0];
+    }
+#ifdef KMCF_CGR_PROFILE
+    if ((blockIdx.x == 0 || blockIdx.x == 17 || blockIdx.x == A.nblocks - 1) && (tid == 0 || tid == 64 || tid == 700))
+        printf("cgr profile block %d thread %d: %d iterations, ticks per iteration: gather %.1f row %.1f red-publish %.1f red-leader %.1f red-wait %.1f (tick = 10 ns)\n",
+               (int)blockIdx.x, tid, iters, (double)tp_gather / max(iters, 1), (double)tp_row / max(iters, 1), (double)tp_red1 / max(iters, 1),
+               (double)tp_red2 / max(iters, 1), (double)tp_red3 / max(iters, 1));
+#endif
+    if (has_row) { A.x[row] = x; A.r[row] = r; }
+    if (blockIdx.x == 0 && tid == 0) {
+        kmcf_scalars h;
+        h.bb = bb; h.rz[0] = h.rz[1] = g_old; h.rz_last = rz_last; h.pAp = pAp;
+        h.red[0] = h.red[1] = h.red[2] = h.red[3] = 0.0;
+        h.alpha[0] = h.alpha[1] = a_old;
+        h.done = done; h.iters = iters; h.x_pending = 0; h.stop_k = 0; h.xa = 0.0;
+        *A.S = h;
+        *A.seq = seq + 1;
+    }
+}
+
+struct cgr_launch_info { int per_cu; size_t lds; };
+
+template <int NQ, int ND, int TPB>
+int cgr_run(const cgr_args &A, bool launch, hipStream_t st, cgr_launch_info *info)
+{
+    const size_t lds = ((size_t)TPB * ND * CGR_W + CGR_NV * 16 + 16) * sizeof(double);
+    auto kern = cgr_kernel<NQ, ND, TPB>;
+    KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (info) {
+        info->lds = lds;
+        KMCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info->per_cu, kern, KMCF_BLOCK * TPB, lds));
+    }
+    if (launch) {
+        kern<<<A.nblocks, KMCF_BLOCK * TPB, lds, st>>>(A);
+        KMCF_HIP(hipGetLastError());
+    }
+    return KMCF_OK;
+}
+
+template <int NQ, int ND>
+int cgr_run_tpb(int tpb, const cgr_args &A, bool launch, hipStream_t st, cgr_launch_info *info)
+{
+    switch (tpb) {
+        case 1: return cgr_run<NQ, ND, 1>(A, launch, st, info);
+        case 2: return cgr_run<NQ, ND, 2>(A, launch, st, info);
+        default: return cgr_run<NQ, ND, 4>(A, launch, st, info);
+    }
+}
+
+int cgr_run_any(const kmcf_matrix *m, int tpb, const cgr_args &A, bool launch, hipStream_t st, cgr_launch_info *info)
+{
+    const int nd = m->dict_n <= 2 ? 2 : 3;
+    switch (m->sell_nq * 10 + nd) {          // the instantiated (steps, dictionary size) pairs of the row-per-lane kernel
+        case 82: return cgr_run_tpb<8, 2>(tpb, A, launch, st, info);
+        case 83: return cgr_run_tpb<8, 3>(tpb, A, launch, st, info);
+        case 132: return cgr_run_tpb<13, 2>(tpb, A, launch, st, info);
+        case 133: return cgr_run_tpb<13, 3>(tpb, A, launch, st, info);
+        case 162: return cgr_run_tpb<16, 2>(tpb, A, launch, st, info);
+        default: return cgr_run_tpb<16, 3>(tpb, A, launch, st, info);
+    }
+}
+
+int cgr_mode()
+{
+    const char *e = getenv("KMCF_CG_RESIDENT");
+    return e ? atoi(e) : 1;                  // 0 off, 1 where a matrix qualifies
+}
+
+}  // namespace
+
+bool kmcf_sell_coded_active(const kmcf_matrix *m);   // kmcf_spmv.hip
+int kmcf_sell_ready(kmcf_matrix *m);                  // ... its stream holds the current value codes
+
+void kmcf_cgr_free(kmcf_matrix *m)
+{
+    kmcf_cgr *g = m->cgr;
+    if (!g) return;
+    if (g->d_zll) hipFree(g->d_zll);
+    if (g->d_slot) hipFree(g->d_slot);
+    if (g->d_gslot) hipFree(g->d_gslot);
+    if (g->d_seq) hipFree(g->d_seq);
+    if (g->d_err) hipFree(g->d_err);
+    if (g->h_err) hipHostFree(g->h_err);
+    delete g;
+    m->cgr = nullptr;
+}
+
+// Plans the resident solve of this matrix (once; the answer is kept): tiles per block and grid such that every block is
+// resident, reduction groups, buffers.  cgr->tpb == 0 afterwards: the matrix does not qualify.
+static int cgr_plan(kmcf_matrix *m)
+{
+    if (m->cgr) return KMCF_OK;
+    kmcf_cgr *g = new kmcf_cgr();
+    m->cgr = g;
+    const kmcf_comm *c = m->comm;
+    // one rank, short rows only, no tunnel block, coded row-per-lane stream with lane t = row r0 + t
+    if (c->nranks > 1 || c->force_collectives || m->n_halo > 0 || m->sub || m->n_short != m->n_loc || m->n_loc == 0 || !m->sell_ok || !m->sell_ident ||
+        m->n_sell_tiles <= 0 || m->sell_lw != KMCF_SLOT_BITS)
+        return KMCF_OK;
+    int cus = 0;
+    KMCF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int share = kmcf_device_share();
+    cgr_args A{};
+    int pick = 0;
+    const int forced = getenv("KMCF_CGR_TPB") ? atoi(getenv("KMCF_CGR_TPB")) : 0;
+    // Tiles per block: the smallest that keeps the grid within 256 blocks -- the flat one-hop reduction needs that, and
+    // more blocks mean more CUs whose LDS pipes share the row sums (measured, us per iteration at 1 / 2 / 4 tiles per
+    // block: 5 nm device, 286 tiles: 8.1 / 6.8 / 8.3; a rank's eighth of the 40 nm matrix, 881 tiles: 14.5 / 14.5 / 11.4);
+    // beyond 1024 tiles: four per block and the two-hop reduction.
+    for (int pass = 0; pass < 2 && !pick; ++pass)
+        for (int tpb : {1, 2, 4}) {
+            if (forced && tpb != forced) continue;
+            const int nb = (m->n_sell_tiles + tpb - 1) / tpb;
+            if (pass == 0 && !forced && nb > 256) continue;
+            if (pass == 1 && !forced && tpb != 4) continue;
+            cgr_launch_info info{0, 0};
+            KMCF_TRY(cgr_run_any(m, tpb, A, false, nullptr, &info));
+            if (info.per_cu >= 1 && nb <= (long long)info.per_cu * cus / share) { pick = tpb; break; }
+        }
+    if (!pick) return KMCF_OK;
+    g->tpb = pick;
+    g->nblocks = (m->n_sell_tiles + pick - 1) / pick;
+    // reduction: flat (g1 = 0: every block reads every block's sums itself, one hop) up to 256 blocks, else by groups of
+    // g1 blocks (two hops); KMCF_CGR_G1 = n forces groups of n
+    int g1 = getenv("KMCF_CGR_G1") ? atoi(getenv("KMCF_CGR_G1")) : (g->nblocks <= 256 ? 0 : 16);
+    if (g1 != 0 || g->nblocks > 256) {
+        g1 = std::max(2, std::min(64, g1));
+        while ((g->nblocks + g1 - 1) / g1 > 64) g1 *= 2;            // one lane per group in the second stage
+        if (g1 > 64) { g->tpb = 0; return KMCF_OK; }
+    }
+    g->g1 = g1;
+    g->ngroups = g1 ? (g->nblocks + g1 - 1) / g1 : 1;
+    g->zwords = 2 * ((size_t)m->n_loc + m->n_halo + 2);
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_zll), 2 * g->zwords * sizeof(u64)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_slot), 2 * (size_t)g->nblocks * CGR_LINE * sizeof(u64)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_gslot), 2 * (size_t)g->ngroups * CGR_LINE * sizeof(u64)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_seq), sizeof(unsigned int)));
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_err), sizeof(int)));
+    KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_err), sizeof(int), hipHostMallocDefault));
+    *g->h_err = 0;
+    g->seq_bound = 0xffffffffull;                                   // (forces the reset below on first use)
+    return KMCF_OK;
+}
+
+bool kmcf_cgr_usable(kmcf_matrix *m)
+{
+    if (cgr_mode() == 0 || !kmcf_sell_coded_active(m)) return false;
+    if (cgr_plan(m) != KMCF_OK) return false;
+    return m->cgr && m->cgr->tpb > 0;
+}
+
+int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks)
+{
+    const bool ok = kmcf_cgr_usable(m);
+    if (tpb) *tpb = ok ? m->cgr->tpb : 0;
+    if (g1) *g1 = ok ? m->cgr->g1 : 0;
+    if (nblocks) *nblocks = ok ? m->cgr->nblocks : 0;
+    return KMCF_OK;
+}
+
+// Enqueues one resident solve on the workspace (m->d_r: b in, r out; m->d_x: x0 in, x out; m->d_dinv), scalars into
+// m->d_S.  The caller synchronises and then calls kmcf_cgr_check.
+int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters)
+{
+    kmcf_cgr *g = m->cgr;
+    KMCF_CHECK(g && g->tpb > 0, KMCF_ERR_STATE, "kmcf_cgr_solve: the matrix has no resident plan");
+    kmcf_comm *c = m->comm;
+    hipStream_t st = c->stream;
+    KMCF_TRY(kmcf_sell_ready(m));
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    // sequence numbers are 32 bits in the LL words and must never repeat within the life of the buffers: well before
+    // the counter could wrap, the buffers are cleared and the counter starts again
+    if (g->seq_bound + (unsigned long long)limit + 16 > 0xf0000000ull) {
+        KMCF_HIP(hipMemsetAsync(g->d_zll, 0, 2 * g->zwords * sizeof(u64), st));
+        KMCF_HIP(hipMemsetAsync(g->d_slot, 0, 2 * (size_t)g->nblocks * CGR_LINE * sizeof(u64), st));
+        KMCF_HIP(hipMemsetAsync(g->d_gslot, 0, 2 * (size_t)g->ngroups * CGR_LINE * sizeof(u64), st));
+        KMCF_HIP(hipMemsetAsync(g->d_seq, 0, sizeof(unsigned int), st));
+        KMCF_HIP(hipMemsetAsync(g->d_err, 0, sizeof(int), st));
+        g->seq_bound = 0;
+    }
+    g->seq_bound += (unsigned long long)limit + 8;
+    static const long long timeout_ms = getenv("KMCF_CGR_TIMEOUT_MS") ? atoll(getenv("KMCF_CGR_TIMEOUT_MS")) : 4000;
+    int rate_khz = 0;
+    KMCF_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
+    cgr_args A{};
+    A.n_tiles = m->n_sell_tiles; A.nblocks = g->nblocks; A.g1 = g->g1; A.ngroups = g->ngroups;
+    A.tile4 = m->d_sell_tile; A.swave = m->d_sell_wave; A.wcol = m->d_sell_wcol;
+    A.stream = reinterpret_cast<const sell_pair *>(m->d_sell);
+    A.dict = m->d_dict; A.diagv = m->d_diagv;
+    A.r = m->d_r; A.x = m->d_x; A.dinv = precond ? m->d_dinv : nullptr;
+    A.S = m->d_S;
+    A.zll = g->d_zll; A.zwords = (long long)g->zwords;
+    A.slot = g->d_slot; A.gslot = g->d_gslot; A.seq = g->d_seq;
+    A.d_err = g->d_err; A.h_err = g->h_err;
+    A.timeout = (long long)rate_khz * timeout_ms;
+    A.limit = limit; A.check_tol = fixed_iters > 0 ? 0 : 1; A.tol2 = tol * tol;
+    return cgr_run_any(m, g->tpb, A, true, st, nullptr);
+}
+
+int kmcf_cgr_check(kmcf_matrix *m)
+{
+    kmcf_cgr *g = m->cgr;
+    if (!g || !g->h_err || *g->h_err == 0) return KMCF_OK;
+    const int code = *g->h_err;
+    *g->h_err = 0;
+    hipMemsetAsync(g->d_err, 0, sizeof(int), m->comm->stream);
+    g->seq_bound = 0xffffffffull;            // whatever the buffers hold now: cleared before the next solve
+    kmcf_set_error("resident CG: a bounded wait expired (%s; KMCF_CGR_TIMEOUT_MS) -- not all blocks of the launch were resident, "
+                   "or the device is shared with a kernel that never ends", code == 11 ? "window gather" : code == 12 ? "group sums" : "final sums");
+    return KMCF_ERR_STATE;
+}

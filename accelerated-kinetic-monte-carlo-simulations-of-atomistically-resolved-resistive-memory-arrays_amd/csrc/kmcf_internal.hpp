@@ -135,6 +135,7 @@ struct kmcf_matrix {
     unsigned int *d_long_ctr = nullptr;
     kmcf_subop *sub = nullptr;         // optional: y[sub rows] += S x_sub after the CSR part (T matrix)
     kmcf_p2p_halo *p2p = nullptr;      // halo landing zone / flags in the peer windows (p2p transport)
+    struct kmcf_cgr *cgr = nullptr;    // plan and buffers of the register-resident solve (kmcf_cgr.hip); tpb == 0: does not qualify
     int row0 = 0;                 // displs[rank]
     int64_t nnz = 0;
     std::vector<int> counts, displs;
@@ -414,6 +415,12 @@ int kmcf_p2p_halo_exchange(kmcf_matrix *m);
 bool kmcf_p2p_direct(const kmcf_matrix *m);
 int kmcf_p2p_direct_put(kmcf_matrix *m, unsigned long long seq, bool skip_if_done);      // standalone put of d_p's sent rows (compute stream)
 int kmcf_p2p_direct_ack(kmcf_matrix *m, unsigned long long seq, bool skip_if_done);      // standalone acknowledgement (compute stream)
+// cgr.hip: register-resident PCG (one launch per solve) for matrices whose tiles are all resident at once
+bool kmcf_cgr_usable(kmcf_matrix *m);
+int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters);
+int kmcf_cgr_check(kmcf_matrix *m);           // after the synchronisation: KMCF_ERR_STATE if a bounded wait expired
+int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks);
+void kmcf_cgr_free(kmcf_matrix *m);
 // matrix.hip
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
                       const int *h_row_ptr, const int *h_col_global, const double *h_val,

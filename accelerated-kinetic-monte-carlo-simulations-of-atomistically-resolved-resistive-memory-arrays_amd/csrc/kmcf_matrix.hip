@@ -443,6 +443,7 @@ extern "C" int kmcf_matrix_destroy(kmcf_matrix *m)
         hipStreamSynchronize(m->comm->comm_stream);
         kmcf_p2p_matrix_free(m);
         kmcf_sell_free(m);
+        kmcf_cgr_free(m);
         void *ptrs[] = {m->d_row_ptr, m->d_col, m->d_val, m->d_boundary_rows, m->d_is_boundary, m->d_send_idx,
                         m->d_send_buf, m->d_halo_gid, m->d_p, m->d_Ap, m->d_r, m->d_x, m->d_dinv,
                         m->d_part_a, m->d_part_b, m->d_part_c, m->d_S, m->d_chunk_row, m->d_perm, m->d_pd, m->d_s,

@@ -1745,6 +1745,9 @@ int kmcf_spmv_device(kmcf_matrix *m, bool with_dot, bool skip_if_done, int flags
     return KMCF_OK;
 }
 
+bool kmcf_sell_coded_active(const kmcf_matrix *m) { return sell_active(m); }
+int kmcf_sell_ready(kmcf_matrix *m) { return sell_refresh(m); }
+
 kmcf_part4 kmcf_spmv_partials(const kmcf_matrix *m)
 {
     kmcf_part4 q;
@@ -1777,6 +1780,7 @@ extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan,
         plan->long_items = m->n_long_items;
         plan->sub_grid = m->sub ? m->sub->grid : 0;
         plan->cg_variant = kmcf_cg_single_reduction(m) ? 1 : 0;
+        if (plan->cg_variant == 1) kmcf_cgr_plan_info(const_cast<kmcf_matrix *>(m), &plan->resident_tpb, &plan->resident_g1, nullptr);
     }
     KMCF_HIP(hipSetDevice(m->comm->device));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));
@@ -1947,6 +1951,7 @@ extern "C" int kmcf_spmv_replan(kmcf_matrix *m)
     if (m->d_diag_pos) { hipFree(m->d_diag_pos); m->d_diag_pos = nullptr; }
     if (m->d_code_fail) { hipFree(m->d_code_fail); m->d_code_fail = nullptr; }
     kmcf_sell_free(m);
+    kmcf_cgr_free(m);                 // (the resident solve's plan follows the row-per-lane layout)
     m->n_tiles = 0;
     m->coded = false;
     m->dict_uploaded = false;

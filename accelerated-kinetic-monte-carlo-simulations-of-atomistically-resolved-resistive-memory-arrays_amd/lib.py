@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmcfield.so")
+# KMCF_LIB_PATH: another build of the SAME library (tools/lab variants with instrumentation compiled in); never a fallback
+LIB_PATH = os.environ.get("KMCF_LIB_PATH") or os.path.join(_HERE, "libkmcfield.so")
 
 KMCF_UNIQUE_ID_BYTES = 256
 
@@ -29,7 +30,8 @@ class SumPlan(C.Structure):
     _fields_ = [("rows", C.c_int), ("n_short", C.c_int), ("halo_cols", C.c_int), ("vec_grid", C.c_int),
                 ("sell_active", C.c_int), ("sell_ident", C.c_int), ("sell_grid", C.c_int), ("sell_tiles", C.c_int),
                 ("boundary_grid", C.c_int), ("boundary_lpr", C.c_int), ("boundary_rows", C.c_int),
-                ("long_items", C.c_int), ("sub_grid", C.c_int), ("cg_variant", C.c_int), ("reserved", C.c_int * 3)]
+                ("long_items", C.c_int), ("sub_grid", C.c_int), ("cg_variant", C.c_int), ("resident_tpb", C.c_int), ("resident_g1", C.c_int),
+                ("reserved", C.c_int * 1)]
 
 
 class TStateInfo(C.Structure):

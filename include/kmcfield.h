@@ -169,7 +169,9 @@ typedef struct {
     int long_items;         /* chunks of the long-row kernel (0: none)                                           */
     int sub_grid;           /* blocks of the tunnel sub-block operator (0: none)                                 */
     int cg_variant;         /* recurrence a solve on this matrix runs now: 0 classic (reference order), 1 single-reduction */
-    int reserved[3];
+    int resident_tpb;       /* > 0: the solve runs as ONE register-resident launch (kmcf_cgr.hip); tiles per block        */
+    int resident_g1;        /* ... blocks per group of its two-stage reduction                                          */
+    int reserved[1];
 } kmcf_sum_plan_t;
 /* h_tile_first / h_tile_rows: first internal row and row count of every row-per-lane tile (sell_tiles entries each;
  * NULL: skip).  h_row_ptr / h_col / h_val: the CSR as stored (internal row order, entries of a row in creation

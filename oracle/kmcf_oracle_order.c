@@ -319,6 +319,131 @@ int orc_pcg1_device_order(int n, const int *rp, const int *col, const double *va
     return iters;
 }
 
+/* The same recurrence as ONE register-resident launch (csrc/kmcf_cgr.hip: cgr_kernel): rows, row sums and the
+ * recurrence as above; what differs is how the dot products are added.  Lane t of tile c holds row tile_first[c] + t
+ * (ONE row per lane; lanes past the tile's rows hold 0); a tile's sum is block_sum of its 256 lanes; block b owns tiles
+ * b tpb ... b tpb + tpb - 1 and adds their sums as T0, T0 + T1 or (T0 + T1) + (T2 + T3); the leader of every group of g1
+ * blocks adds its group with one lane per block (wave_sum64, idle lanes 0); every block adds the group sums with one
+ * lane per group (wave_sum64).  The last r.z of a loop that ends on its iteration limit is formed the same way. */
+static double resident_block_sum(const double *lane_val, int n_tiles, int tpb, int b)
+{
+    double T[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < tpb; ++j) {
+        const int c = b * tpb + j;
+        if (c < n_tiles) T[j] = block_sum(lane_val + (size_t)c * BLK);
+        else {                                           /* a block's idle tile: 256 lanes of 0.0 */
+            double zero[BLK];
+            for (int t = 0; t < BLK; ++t) zero[t] = 0.0;
+            T[j] = block_sum(zero);
+        }
+    }
+    return tpb == 1 ? T[0] : (tpb == 2 ? T[0] + T[1] : (T[0] + T[1]) + (T[2] + T[3]));
+}
+
+static double resident_sum(const double *lane_val /* n_tiles x BLK */, int n_tiles, int tpb, int g1)
+{
+    const int nblocks = (n_tiles + tpb - 1) / tpb;
+    if (g1 == 0) {
+        /* flat reduction (<= 256 blocks): lane l of wave w holds block 64 w + l (idle lanes 0); wave_sum64 each, then
+         * (w0 + w1) + (w2 + w3) */
+        double ws[4];
+        for (int w = 0; w < 4; ++w) {
+            double blk[64];
+            for (int l = 0; l < 64; ++l) blk[l] = 64 * w + l < nblocks ? resident_block_sum(lane_val, n_tiles, tpb, 64 * w + l) : 0.0;
+            ws[w] = wave_sum64(blk);
+        }
+        return (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    }
+    const int ngroups = (nblocks + g1 - 1) / g1;
+    double grp[64];
+    for (int l = 0; l < 64; ++l) grp[l] = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        double blk[64];
+        for (int l = 0; l < 64; ++l) blk[l] = 0.0;
+        for (int l = 0; l < g1 && g * g1 + l < nblocks; ++l) blk[l] = resident_block_sum(lane_val, n_tiles, tpb, g * g1 + l);
+        grp[g] = wave_sum64(blk);
+    }
+    return wave_sum64(grp);
+}
+
+int orc_pcg1_resident_order(int n, const int *rp, const int *col, const double *val, double *r, double *x, const double *dinv,
+                            int precond, double tol, int max_it, int fixed_iters, int tpb, int g1, int n_tiles,
+                            const int *tile_first, const int *tile_rows, double *bb_out, double *rz_out, int *done_out,
+                            double *rz_hist)
+{
+    double *z = (double *)malloc(((size_t)n + 1) * sizeof(double));
+    double *w = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *p = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *sv = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *la = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    double *lb = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    double *lc = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    const double tol2 = tol * tol;
+#define FOR_LANES(...)                                                           \
+    for (int c = 0; c < n_tiles; ++c)                                            \
+        for (int t = 0; t < tile_rows[c]; ++t) {                                 \
+            const int i = tile_first[c] + t;                                     \
+            const size_t L = (size_t)c * BLK + t;                                \
+            __VA_ARGS__                                                          \
+        }
+    for (int i = 0; i < n; ++i) w[i] = row_sum_diag_last(i, rp, col, val, x);                 /* A x0 */
+    FOR_LANES({
+        const double b = r[i];
+        lc[L] = b * b;
+        const double ri = b + (-1.0) * w[i];
+        r[i] = ri;
+        z[i] = ri * (precond ? dinv[i] : 1.0);
+        la[L] = ri * z[i];
+    })
+    double bb = 0.0, g_old = 0.0, a_old = 0.0, rz_last = 0.0;
+    int iters = 0, done = 0;
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    for (int k = 1; k <= limit; ++k) {
+        const int first = k == 1;
+        for (int i = 0; i < n; ++i) w[i] = row_sum_diag_last(i, rp, col, val, z);
+        FOR_LANES({ lb[L] = z[i] * w[i]; })
+        const double gamma = resident_sum(la, n_tiles, tpb, g1);
+        const double delta = resident_sum(lb, n_tiles, tpb, g1);
+        if (first) bb = resident_sum(lc, n_tiles, tpb, g1);
+        const int go = fixed_iters > 0 ? 1 : (gamma / bb > tol2);
+        rz_last = gamma;
+        if (rz_hist) rz_hist[k - 1] = gamma;
+        if (!go) { done = 1; break; }
+        double beta = 0.0, alpha;
+        if (first) alpha = gamma / delta;
+        else {
+            beta = gamma / g_old;
+            alpha = gamma / (delta - beta * gamma / a_old);
+        }
+        g_old = gamma;
+        a_old = alpha;
+        iters += 1;
+        const double na = -alpha;
+        FOR_LANES({
+            const double zi = z[i], wi = w[i];
+            const double pi = first ? zi : zi + beta * p[i];
+            const double si = first ? wi : wi + beta * sv[i];
+            p[i] = pi;
+            sv[i] = si;
+            x[i] = x[i] + alpha * pi;
+            const double ri = r[i] + na * si;
+            r[i] = ri;
+            z[i] = ri * (precond ? dinv[i] : 1.0);
+            la[L] = ri * z[i];
+        })
+    }
+    if (!done) {
+        rz_last = resident_sum(la, n_tiles, tpb, g1);
+        if (rz_hist) rz_hist[limit] = rz_last;
+    }
+#undef FOR_LANES
+    *bb_out = bb;
+    *rz_out = rz_last;
+    *done_out = done;
+    free(z); free(w); free(p); free(sv); free(la); free(lb); free(lc);
+    return iters;
+}
+
 /* y = A x in the row-per-lane kernel's order (for SpMV parity at bit level) */
 void orc_spmv_device_order(int n_tiles, const int *tile_first, const int *tile_rows, int sell_grid, const int *rp,
                            const int *col, const double *val, const double *x, double *y)

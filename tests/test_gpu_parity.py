@@ -308,10 +308,14 @@ def test_total_potential_against_reference_snapshot(km, sys5, ref5):
     assert np.median(err) <= 1e-5 and np.percentile(err, 90) <= 1e-3, (np.median(err), np.percentile(err, 90))
 
 
-def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle):
+@pytest.mark.parametrize("resident", [1, 0])
+def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle, resident):
     """KMCF_CG_VARIANT=cg1r (Chronopoulos-Gear, the default of multi-rank groups): same Krylov iterates in
-    exact arithmetic, one fused reduction per iteration.  Same stopping rule, same bars as the classic loop."""
+    exact arithmetic, one fused reduction per iteration.  Same stopping rule, same bars as the classic loop.
+    resident = 1: the whole solve as ONE register-resident launch (csrc/kmcf_cgr.hip; the 5 nm system's 143 tiles
+    are all resident at once); 0: two kernels per iteration (pcg1_loop).  Each against the oracle adding in ITS order."""
     import os
+    os.environ["KMCF_CG_RESIDENT"] = str(resident)
     torch = torch_cuda
     S = km.solvers
     buf, d = sys5["buf"], sys5["d"]
@@ -328,12 +332,14 @@ def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle):
         r40 = torch.as_tensor(A["rhs"], device="cuda").clone()
         x40 = torch.zeros_like(r40)
         st40 = S.conjugate_gradient_jacobi(mat, r40, x40, dinv, ref5["tol"], 40)
+        plan = mat.sum_plan()
     finally:
         del os.environ["KMCF_CG_VARIANT"]
+        del os.environ["KMCF_CG_RESIDENT"]
     assert st["converged"] == 1 and st["relres"] <= ref5["tol"]
+    assert (plan["resident_tpb"] > 0) == bool(resident), plan["resident_tpb"]
     # a different recurrence (Chronopoulos-Gear): the same iterates as the reference's only in exact arithmetic.
     # Held to the oracle's restatement of THIS recurrence in the device's order: identical
-    plan = mat.sum_plan()
     orc = oracle.pcg_device_order(plan, A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"], 10000, variant="cg1r")
     assert_solve_bit_identical(st, x.cpu().numpy(), r.cpu().numpy(), orc)
     orc40 = oracle.pcg_device_order(plan, A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"], 40, variant="cg1r")

@@ -195,3 +195,36 @@ def test_heat_update_closed_form(oracle):
     T = oracle.update_temperature_global(p, 300.0, 0.5, 10.0, 3.0, 1e-6, 1e-3)
     c = 10.0 + 2e-6 / 1e-6 * 1e-3
     assert T == pytest.approx(c * (1 - 0.5 ** 3) / 0.5 + 0.5 ** 3 * 300.0, rel=1e-15)
+
+
+def test_resident_order_restatement_is_the_same_recurrence(oracle, ref5):
+    """oracle/kmcf_oracle_order.c: orc_pcg1_resident_order (the summation order of the register-resident solve,
+    csrc/kmcf_cgr.hip) against orc_pcg1_device_order (the two-kernel loop) on a hand-made plan: the same
+    single-reduction recurrence, dots added along two different trees -- iterates agree to rounding for as long as the
+    recurrence is insensitive to it (40 iterations), and the converged solves sit within the summation-order spread
+    of this system (conftest.py: counts 316 ... 328, potentials 5e-4 V)."""
+    import numpy as np
+    A, ks = ref5["A"], ref5["ks"]
+    n = ks.n
+    first = np.arange(0, n, 256, dtype=np.int32)
+    rows = np.minimum(256, n - first).astype(np.int32)
+    base = dict(rows=n, n_short=n, halo_cols=0, vec_grid=72, sell_active=1, sell_ident=1, sell_grid=(len(first) + 7) // 8 * 8, sub_grid=0,
+                cg_variant=1, tile_first=first, tile_rows=rows, row_ptr=ks.row_ptr, col=ks.col, val=A["val"],
+                perm=np.arange(n, dtype=np.int32))
+    out = {}
+    for name, extra in (("loop", dict(resident_tpb=0, resident_g1=0)), ("tpb4", dict(resident_tpb=4, resident_g1=16)),
+                        ("tpb1", dict(resident_tpb=1, resident_g1=8)), ("flat", dict(resident_tpb=2, resident_g1=0))):
+        plan = dict(base, **extra)
+        out[name] = (oracle.pcg_device_order(plan, A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 40),
+                     oracle.pcg_device_order(plan, A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 10000))
+    for name in ("tpb4", "tpb1", "flat"):
+        a40, a = out[name]
+        b40, b = out["loop"]
+        assert a40["iterations"] == b40["iterations"] == 40
+        assert np.abs(a40["x"] - b40["x"]).max() <= 1e-9
+        np.testing.assert_allclose(a40["rz"], b40["rz"], rtol=1e-6)
+        assert a["converged"] and abs(a["iterations"] - b["iterations"]) <= 0.05 * b["iterations"]
+        assert np.abs(a["x"] - ref5["x"]).max() <= 5e-4
+        assert np.sqrt(a["rz"] / a["bb"]) <= ref5["tol"]
+    # the two trees are different computations: not bit-identical (or the test would prove nothing about the tree)
+    assert not np.array_equal(out["tpb4"][1]["x"], out["loop"][1]["x"]) or not np.array_equal(out["tpb1"][1]["x"], out["loop"][1]["x"])

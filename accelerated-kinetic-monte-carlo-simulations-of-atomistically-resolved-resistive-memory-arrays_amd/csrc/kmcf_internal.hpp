@@ -226,6 +226,7 @@ struct kmcf_matrix {
     bool sell_dirty = true;            // codes in d_idx16 are newer than d_sell
     std::vector<int> h_sell_cuts;      // end row of every tile, fixed by kmcf_sell_refine_order (empty: plan_sell cuts greedily)
     bool sell_ident = false;           // every tile's rows are already sorted by length: lane t owns row r0 + t
+    bool sell_nt = false;              // the coded entry stream is larger than the Infinity Cache: loaded nontemporal
     int sell_lw = 10, sell_nq = 0;     // log2 of the window slots per class; steps of 4 entries held in registers
     int n_sell_tiles = 0, sell_grid = 0;
     int64_t n_sell_wcols = 0, n_sell_entries = 0;

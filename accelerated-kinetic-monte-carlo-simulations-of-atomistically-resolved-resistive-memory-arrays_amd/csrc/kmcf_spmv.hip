@@ -402,11 +402,11 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_wcode_kernel(
 typedef unsigned int sell_pair __attribute__((ext_vector_type(2)));   // 4 entries
 // the stream is loaded with plain (cacheable) loads -- see stream_load above; -DKMCF_SELL_NT_LAB is the
 // nontemporal variant of the measurements in tools/lab/big_lab.sh
-#ifdef KMCF_SELL_NT_LAB
-#define KMCF_SELL_LD(p) __builtin_nontemporal_load(p)
-#else
-#define KMCF_SELL_LD(p) (*(p))
-#endif
+// (NT: the matrix's own stream beyond the Infinity Cache, kmcf_matrix::sell_nt -- the hint keeps the stream from
+// evicting x there: 12 x 12-cell device, 350 MB of format, 67.5 us against 71.0; never inside the cache: 31.9 against 25.2)
+#define KMCF_SELL_LD(p) stream_load<NT>(p)
+// (the window map and the diagonal -- read once per launch, too -- under the same hint: 77.6 us against 68.2, dropped)
+#define KMCF_SELL_LD2(p) (*(p))
 
 template <int WQ>
 struct sell_regs {
@@ -416,7 +416,7 @@ struct sell_regs {
     bool valid;
 };
 
-template <int NQ, int LW, int ND, bool DOT, bool SKIP_BOUNDARY, bool IDENT>
+template <int NQ, int LW, int ND, bool DOT, bool SKIP_BOUNDARY, bool IDENT, bool NT = false>
 __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
     int n_tiles, const int4 *__restrict__ tile4, const int2 *__restrict__ swave, const int *__restrict__ lrow,
     const int *__restrict__ wcol, const sell_pair *__restrict__ stream, const double *__restrict__ x, double *__restrict__ y,
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
         // stage B: window map (and lane rows) of a tile
         auto load_b = [&](int c, const int4 &d, int (&wc)[WQ], int &lr) {
 #pragma unroll
-            for (int q = 0; q < WQ; ++q) wc[q] = wcol[d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0))];
+            for (int q = 0; q < WQ; ++q) wc[q] = KMCF_SELL_LD2(wcol + d.z + min(q * KMCF_BLOCK + tid, max(d.w - 1, 0)));
             if (!IDENT) lr = lrow[(size_t)c * KMCF_BLOCK + tid];
         };
         // the same with (wave-scope, relaxed) atomic loads, which stay where they are written and cost nothing
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             }
             t.xrow = x[t.row];
             t.xown = IDENT ? t.xrow : x[d.x + min(tid, d.y - 1)];
-            t.dg = diagv[t.row];
+            t.dg = KMCF_SELL_LD2(diagv + t.row);
             if (SKIP_BOUNDARY) t.valid = t.valid && is_boundary[t.row] == 0;
             t.nq = sw.y;
             t.wn = d.w;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void spmv_sell_kernel(
             }
             if (cur.valid) {
                 s += cur.dg * cur.xrow;
-                y[cur.row] = s;
+                y[cur.row] = s;                       // (a nontemporal store here under NT: no gain, 68.5-74.6 against 67.1-70.3 us)
                 if (DOT) dot += cur.xrow * s;
             }
         };
@@ -985,6 +985,13 @@ int sell_dispatch1(kmcf_matrix *m, bool launch, bool with_dot, bool skip_if_done
     double *part = with_dot ? m->d_part_a : nullptr;
     const int grid = launch ? m->sell_grid : 0;
     int pc = 0;
+    if constexpr (IDENT) {
+        if (!skipb && m->sell_nt && launch) {            // (same registers and LDS: the occupancy query of the plain instance holds)
+            if (with_dot) run_or_query(spmv_sell_kernel<NQ, LW, ND, true, false, true, true>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+            else run_or_query(spmv_sell_kernel<NQ, LW, ND, false, false, true, true>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
+            return pc;
+        }
+    }
     if (with_dot) {
         if (skipb) run_or_query(spmv_sell_kernel<NQ, LW, ND, true, true, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
         else run_or_query(spmv_sell_kernel<NQ, LW, ND, true, false, IDENT>, launch, &pc, grid, st, KMCF_SELL_ARGS(isb, part));
@@ -1475,6 +1482,10 @@ int plan_sell(kmcf_matrix *m, const std::vector<int> &col)
     m->sell_ident = ident;
     m->sell_ok = true;
     m->sell_grid = 0;                                 // with the dictionary (its size selects the instance)
+    // beyond the Infinity Cache (256 MiB; 10 x 10 cells = 243 MB of format still run 40.2 us plain against 51.9
+    // nontemporal) the entry stream is loaded nontemporal; KMCF_SELL_NT overrides
+    m->sell_nt = 2.0 * (double)st.size() + 4.0 * (double)wcol.size() + 28.0 * (double)n > 300e6;
+    if (const char *e = getenv("KMCF_SELL_NT")) m->sell_nt = atoi(e) != 0;
     return KMCF_OK;
 }
 

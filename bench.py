@@ -438,14 +438,22 @@ def main():
     if world == 1 and os.path.exists(tpath):
         tj = json.load(open(tpath))
         entries = tj["kernels"] if "kernels" in tj else [tj]
+        # a committed figure is only reported for the kernel source it was measured on (tools/pmc_summary.py stamps
+        # the hash of csrc/kmcf_spmv.hip + kmcf_internal.hpp); after any change of those files: null until re-profiled
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        sha_now = pmc_summary.kernel_source_sha()
         for blk in (roofline, roofline_csr, roofline_hbm, roofline_f64):
             if blk is None or "kernel" not in blk:
                 continue
             for e in entries:
                 if e.get("rows") == blk.get("rows", n_loc) and e.get("workload") == blk.get("workload", d["name"]) and \
                         e.get("kernel", "").split("<")[0] == blk["kernel"].split(" ")[0]:
-                    blk["traffic"] = e["corrected_bytes_per_launch"]
-                    blk["traffic_source"] = e.get("source", "profiles/spmv_traffic.json")
+                    if e.get("source_sha") == sha_now:
+                        blk["traffic"] = e["corrected_bytes_per_launch"]
+                        blk["traffic_source"] = e.get("source", "profiles/spmv_traffic.json")
+                    else:
+                        blk["traffic_stale"] = "profiles/spmv_traffic.json was measured on kernel source %s, this is %s" % (e.get("source_sha"), sha_now)
 
     # ---- CPU baseline: the oracle's OpenMP PCG (same op sequence) on the host cores ---------
     cpu = None

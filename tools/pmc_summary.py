@@ -11,8 +11,19 @@ kernels with a known byte count (cg_p_kernel reads 4 vectors -- r, 1/diag, p, x 
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def kernel_source_sha():
+    """What bench.py compares before it reports a committed traffic figure: the SpMV kernels' source as profiled."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*_amd", "csrc", "kmcf_spmv.hip")) + glob.glob(os.path.join(root, "*_amd", "csrc", "kmcf_internal.hpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(d):
@@ -51,7 +62,7 @@ def main():
             continue
         corrected = 2.0 * sp[2] * 1024 + sp[3] * 1024
         e = dict(kernel=sp[0], calls=sp[1], fetch_kib=sp[2], write_kib=sp[3], fetch_factor=2.0,
-                 corrected_bytes_per_launch=int(corrected), rows=n_rows)
+                 corrected_bytes_per_launch=int(corrected), rows=n_rows, source_sha=kernel_source_sha())
         if workload:
             e["workload"] = workload
         kernels.append(e)

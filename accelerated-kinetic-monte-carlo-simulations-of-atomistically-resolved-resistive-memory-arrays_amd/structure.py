@@ -108,11 +108,16 @@ def _stripes(coord, length, n_lines, fill):
     return (coord % period) < fill * period
 
 
-def synth_crossbar_40nm(tiles=8, fill=0.52, n_lines=2, vacancy_fraction=0.05, seed=40, carve=True, order="bwmin"):
+def synth_crossbar_40nm(tiles=8, fill=0.52, n_lines=2, vacancy_fraction=0.05, seed=40, carve=True, order="bwmin", filament=None):
     """Synthetic 40 nm crossbar (see module docstring).  Deterministic for a given seed
     (numpy PCG64); with the defaults: ~1.63e6 interface rows, ~25 nnz/row.
 
     tiles: the 5 nm cell is repeated tiles x tiles in (y, z), period 51.15 A.
+    filament: radius in Angstrom (None: none) of a conductive filament at the first crossing of a word line and a bit
+      line: every oxygen site inside a cylinder along x becomes a vacancy.  Such vacancies have >= 2 vacancy neighbours,
+      so the charge rule leaves them uncharged (src/potential_solver_gpu.cu:12-63) and neighbouring ones are joined by
+      high_G (populate_T_dist, src/current_solver_gpu.cu:1139-1243): a path from electrode to electrode, which the
+      random 5 % of vacancies alone does not form (its macroscopic current is zero +- the solver's residual).
     carve: bottom electrode (x below the oxide) kept on `n_lines` word lines (stripes in z,
       running along y), top electrode + Ti reservoir kept on `n_lines` bit lines (stripes in
       y), oxide and interstitial sites kept under either set of lines.
@@ -151,6 +156,10 @@ def synth_crossbar_40nm(tiles=8, fill=0.52, n_lines=2, vacancy_fraction=0.05, se
     o_idx = np.flatnonzero(el == O_EL)
     pick = rng.choice(o_idx, size=int(round(vacancy_fraction * len(o_idx))), replace=False)
     el[pick] = VACANCY
+    if filament:
+        half = 0.5 * fill * L / n_lines            # centre of the first stripe of either set of lines
+        inside = (xyz[:, 1] - half) ** 2 + (xyz[:, 2] - half) ** 2 <= float(filament) ** 2
+        el[inside & (el == O_EL)] = VACANCY
     # site order: outer contact layers first / last (they are the Dirichlet boundary), rest by `order`
     xx = xyz[:, 0]
     left = np.flatnonzero(np.abs(xx - x_left_layer) < 1e-6)
@@ -179,7 +188,8 @@ def synth_crossbar_40nm(tiles=8, fill=0.52, n_lines=2, vacancy_fraction=0.05, se
     return dict(xyz=xyz, element=el, lattice=np.array([108.98, L, L]), N=len(el), N_contact=len(left),
                 metals=base["metals"], Vd=15.0,              # structures/40nm_crossbar/parameters.txt:42
                 nn_dist=3.5, pbc=0, sigma=3.5e-10, k=base["k"], high_G=1.0, low_G=1e-8,
-                name="synthetic_40nm_crossbar(tiles=%d,fill=%.2f,lines=%d,seed=%d,%s)" % (tiles, fill, n_lines, seed, order))
+                name="synthetic_40nm_crossbar(tiles=%d,fill=%.2f,lines=%d,seed=%d,%s%s)"
+                     % (tiles, fill, n_lines, seed, order, ",filament=%g" % filament if filament else ""))
 
 
 def synth_small(tiles=1, seed=1, order="bwmin", fill=1.0):

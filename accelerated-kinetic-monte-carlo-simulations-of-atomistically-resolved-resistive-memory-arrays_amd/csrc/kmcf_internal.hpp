@@ -349,6 +349,16 @@ struct kmcf_subop {
     int *d_strip_first = nullptr;            // nb + 1: first strip of every block row
     double *d_rowpart = nullptr, *d_colpart = nullptr;   // 2 x 64 per strip / 2 x 64 per tile (the power pass needs two sums)
     size_t cap_tiles = 0, cap_strips = 0, cap_sf = 0, cap_rowpart = 0, cap_colpart = 0;
+    // ... or (jagged, with dense set: strips, parts and their reduction are shared) the same tiles holding only their
+    // ENTRIES: tile-major row masks + the values in layers (kmcf_tstate.hip: sub_symj_kernel) -- 4 B per entry of the
+    // full block + 1 bit per position instead of 4 B per position
+    bool jagged = false;
+    unsigned long long *d_jmask = nullptr;   // n_tiles x 64
+    long long *d_jvoff = nullptr;            // n_tiles + 1: first value of every tile
+    double *d_jval = nullptr;
+    int *d_jcnt = nullptr;                   // entries per tile (scan input)
+    long long jnnz = 0;                      // stored entries (upper tiles + complete diagonal tiles)
+    size_t cap_jmask = 0, cap_jvoff = 0, cap_jval = 0, cap_jcnt = 0;
 };
 
 // ---------------------------------------------------------------- internal entry points

@@ -697,9 +697,10 @@ __global__ __launch_bounds__(KMCF_BLOCK) void tunnel_dense_fill_kernel(
 template <int MODE>
 __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_kernel(int n_strips, const int4 *__restrict__ strips, const double *__restrict__ tiles,
                                                               const double *__restrict__ x, double Vd, double *__restrict__ rowpart,
-                                                              double *__restrict__ colpart)
+                                                              double *__restrict__ colpart, const kmcf_scalars *__restrict__ S, int check_done)
 {
     extern __shared__ double sym_lds[];
+    if (check_done && S->done) return;                  // (iterations enqueued behind the stop: nothing to stream)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *T = sym_lds + (size_t)wv * SYM_WAVE_DOUBLES;
     double *xI = T + 64 * SYM_LD, *xJ = xI + 64;
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_kernel(int n_strips, cons
             __builtin_amdgcn_wave_barrier();
             const bool diag = J == I;
             if (MODE == 0) {
+                // (x_J / x_I through v_readlane instead of LDS broadcasts: 0.296 against 0.280 ms per iteration -- the kernel is bound by its stream)
 #pragma unroll 8
                 for (int c = 0; c < 64; ++c) ra += T[lane * SYM_LD + c] * xJ[c];
                 if (!diag) {
@@ -772,6 +774,269 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_kernel(int n_strips, cons
         }
         if (MODE == 0) rowpart[(size_t)s * 64 + lane] = ra;
         else { rowpart[(size_t)s * 128 + lane] = ra; rowpart[(size_t)s * 128 + 64 + lane] = rb; }
+    }
+}
+
+// ---------------------------------------------------------------- jagged symmetric tiles (kmcf_subop::jagged)
+// The upper block triangle again (tile index, strips, row / column parts and their reduction exactly as above), but a
+// tile stores only its ENTRIES: the 64 row masks of the pattern (tile-major copy of the bitmap's words) and the values
+// in "layers" -- layer k holds the k-th entry of every row that has more than k entries, rows ascending, without gaps
+// (a jagged-diagonal layout inside the tile): 4 B per entry of the full block + 1 bit per position, against 4 B per
+// POSITION for the dense tiles -- the reference's contact window (44 % full) moves 2.1 x fewer bytes, and the sums are
+// the SAME sums: lane r adds row r's products in ascending column order (an absent entry added 0.0 before), lane c
+// the tile's column c top-down out of a dense copy of the tile in LDS.  One load instruction per layer, lane r
+// reading base_k + (number of rows below r in the layer): consecutive lanes, consecutive addresses.
+typedef unsigned long long symj_u64;
+
+// largest of the lanes' values (0 ... 64), through ballots: scalar work only (a shuffle butterfly is six trips through
+// the LDS crossbar, ~0.4 us -- per tile)
+__device__ __forceinline__ int symj_wave_max(int v)
+{
+    symj_u64 live = ~0ull;
+    int r = 0;
+#pragma unroll
+    for (int bit = 6; bit >= 0; --bit) {
+        const symj_u64 b = __ballot((v >> bit) & 1) & live;
+        if (b) { live = b; r |= 1 << bit; }
+    }
+    return r;
+}
+
+// element `l` (a compile-time constant in the unrolled loops) of a 64-vector held one element per lane
+__device__ __forceinline__ double symj_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// tile-major masks + entries per tile
+__global__ __launch_bounds__(KMCF_BLOCK) void symj_mask_kernel(int n_strips, const int4 *__restrict__ strips, int n_glob, int n_groups,
+                                                               const symj_u64 *__restrict__ mask, symj_u64 *__restrict__ jmask, int *__restrict__ tcnt)
+{
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < n_strips; s += gridDim.x * 4) {
+        const int4 st = strips[s];
+        const int i = 64 * st.x + lane;
+        for (int q = 0; q < st.z; ++q) {
+            const symj_u64 w = i < n_glob ? mask[(size_t)i * n_groups + st.y + q] : 0ull;
+            jmask[((size_t)st.w + q) * 64 + lane] = w;
+            int c = __popcll(w);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+            if (lane == 0) tcnt[st.w + q] = c;
+        }
+    }
+}
+
+// values in layer order (populate_T_tunnel_dist2 on the tile's entries; the diagonal entry 0 until symj_set_diag_kernel)
+__global__ __launch_bounds__(KMCF_BLOCK) void symj_fill_kernel(
+    int n_strips, const int4 *__restrict__ strips, int n_glob, const int *__restrict__ tinfo, const double *__restrict__ tx,
+    const double *__restrict__ ty, const double *__restrict__ tz, const double *__restrict__ tcb, double tol, double m_e, double V0,
+    const symj_u64 *__restrict__ jmask, const long long *__restrict__ jvoff, double *__restrict__ jval)
+{
+    const int lane = threadIdx.x & 63;
+    const symj_u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < n_strips; s += gridDim.x * 4) {
+        const int4 st = strips[s];
+        const int i = 64 * st.x + lane;
+        const bool iin = i < n_glob;
+        const double xi = iin ? tx[i] : 0.0, yi = iin ? ty[i] : 0.0, zi = iin ? tz[i] : 0.0, cbi = iin ? tcb[i] : 0.0;
+        const int fi = iin ? tinfo[i] : 0;
+        for (int q = 0; q < st.z; ++q) {
+            const size_t t = (size_t)st.w + q;
+            symj_u64 m = jmask[t * 64 + lane];
+            long long base = jvoff[t];
+            while (true) {
+                const symj_u64 b = __ballot(m != 0);
+                if (!b) break;
+                if (m) {
+                    const int j = 64 * (st.y + q) + __builtin_ctzll(m);
+                    m &= m - 1;
+                    double v = 0.0;
+                    if (j != i) {
+                        bool c2t;
+                        const double cbj = tcb[j];
+                        tunnel_pair(fi, tinfo[j], cbi, cbj, tol, &c2t);
+                        v = wkb_value(dist3(xi, yi, zi, tx[j], ty[j], tz[j]), cbi, cbj, c2t, m_e, V0);
+                    }
+                    jval[base + __popcll(b & lt)] = v;
+                }
+                base += __popcll(b);
+            }
+        }
+    }
+}
+
+// tdiag = -(row sums) into the diagonal tiles' diagonal entries (calc_diagonal_T_tunnel, :669-689); a wave per block row
+__global__ __launch_bounds__(KMCF_BLOCK) void symj_set_diag_kernel(int n_glob, int nb, const double *__restrict__ rowsum, double *__restrict__ tdiag,
+                                                                   const symj_u64 *__restrict__ jmask, const long long *__restrict__ jvoff,
+                                                                   double *__restrict__ jval)
+{
+    const int lane = threadIdx.x & 63;
+    const symj_u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int B = blockIdx.x * 4 + (threadIdx.x >> 6); B < nb; B += gridDim.x * 4) {
+        const size_t t = (size_t)symm_tile_index(nb, B, B);
+        const symj_u64 m = jmask[t * 64 + lane];
+        const int cnt = __popcll(m), kl = __popcll(m & lt), i = 64 * B + lane;
+        long long pos = jvoff[t];
+        for (int k = 0; k < 64; ++k) {
+            const symj_u64 b = __ballot(cnt > k);
+            if (!b) break;
+            if (k < kl) pos += __popcll(b);
+            else if (k == kl) pos += __popcll(b & lt);
+        }
+        if (i < n_glob && ((m >> lane) & 1ull)) {
+            const double d = -rowsum[i];
+            tdiag[i] = d;
+            jval[pos] = d;
+        }
+    }
+}
+
+// One pass over the stored tiles: the jagged twin of sub_symm_kernel (same parts into rowpart / colpart, MODE as there).
+// Per tile ONE wait for memory, at the top, for loads that were all requested a tile earlier, before the passes over
+// the dense copy: this tile's layers (a lane past its row's end re-reads the layer's first word: no divergent loads),
+// the next tile's masks and x_J.  Control flow is scalar (the strip walk is per wavefront), the scatter into the dense
+// copy and its removal are branch-free (idle lanes write a dump word).
+template <int MODE>
+__global__ __launch_bounds__(KMCF_BLOCK) void sub_symj_kernel(int n_strips, const int4 *__restrict__ strips, const symj_u64 *__restrict__ jmask,
+                                                              const long long *__restrict__ jvoff, const double *__restrict__ jval,
+                                                              const double *__restrict__ x, double Vd, double *__restrict__ rowpart,
+                                                              double *__restrict__ colpart, const kmcf_scalars *__restrict__ S, int check_done)
+{
+    extern __shared__ double sym_lds[];
+    if (check_done && S->done) return;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const symj_u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    double *T = sym_lds + (size_t)wv * SYM_WAVE_DOUBLES;
+    double *xI = T + 64 * SYM_LD, *xJ = xI + 64, *dump = xJ + 64;      // (dump: 64 words of the wave's four spare 64-vectors)
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) T[lane * SYM_LD + c] = 0.0;           // the dense copy: entries in, entries out again per tile
+    const int ds = gridDim.x * 4;
+    int s = blockIdx.x * 4 + wv;                                       // (scalar)
+    if (s >= n_strips) return;
+    int4 st = strips[s];
+    st.x = __builtin_amdgcn_readfirstlane(st.x); st.y = __builtin_amdgcn_readfirstlane(st.y);
+    st.z = __builtin_amdgcn_readfirstlane(st.z); st.w = __builtin_amdgcn_readfirstlane(st.w);
+    int q = 0;
+    double v[64];
+    auto request = [&](symj_u64 m, long long base) {                   // the layers of a tile (in eights, up to its deepest)
+        const int cnt_ = __popcll(m), kmax_ = symj_wave_max(cnt_);
+        const double *src = jval + base;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if ((k & 7) == 0 && k >= kmax_) break;
+            const symj_u64 b = __ballot(cnt_ > k);
+            v[k] = __builtin_nontemporal_load(src + (cnt_ > k ? __popcll(b & lt) : 0));
+            src += __popcll(b);
+        }
+    };
+    // the tile after (s, q) of this wave's walk (scalar): the next of the strip, or the first of the wave's next strip
+    auto step = [&](const int4 &a, int sa, int qa, int4 &b, int &sb_, int &qb) -> bool {
+        b = a; sb_ = sa; qb = qa + 1;
+        if (qb < a.z) return true;
+        if (sa + ds >= n_strips) return false;
+        sb_ = sa + ds;
+        b = strips[sb_];
+        b.x = __builtin_amdgcn_readfirstlane(b.x); b.y = __builtin_amdgcn_readfirstlane(b.y);
+        b.z = __builtin_amdgcn_readfirstlane(b.z); b.w = __builtin_amdgcn_readfirstlane(b.w);
+        qb = 0;
+        return true;
+    };
+    symj_u64 m0 = jmask[(size_t)st.w * 64 + lane];
+    int4 st1; int s1, q1;
+    bool have1 = step(st, s, q, st1, s1, q1);
+    symj_u64 m1 = have1 ? jmask[((size_t)st1.w + q1) * 64 + lane] : 0ull;      // masks run one tile ahead of the values
+    request(m0, jvoff[st.w]);
+    double xjn = x[64 * st.y + lane];
+    xI[lane] = x[64 * st.x + lane];
+    double ra = 0.0, rb = 0.0;
+    while (true) {
+        const int I = st.x, J = st.y + q;
+        const size_t t = (size_t)st.w + q;
+        const bool diag = J == I;
+        const bool more = q + 1 < st.z;
+        // ---- this tile's layers are in v (the one wait); entries into the dense copy
+        xJ[lane] = xjn;
+        const double xi_l = xI[lane], xj_l = xjn;                      // x_I / x_J, one element per lane (columns: readlane)
+        const int cnt = __popcll(m0), kmax = symj_wave_max(cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            // entries into the dense copy
+            symj_u64 m = m0;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                if ((k & 7) == 0 && k >= kmax) break;                  // (scalar; k is a compile-time constant in the unrolled body)
+                const bool on = m != 0;
+                const int c = on ? __builtin_ctzll(m) : 0;
+                m &= m - 1;
+                double *dst = on ? T + lane * SYM_LD + c : dump + lane;
+                *dst = v[k];
+            }
+        }
+        // ---- the next tile's masks arrived with them: its layers, its x_J and the masks of the tile after it go out now
+        // and are in flight during the passes over the dense copy
+        int4 st2 = st1; int s2 = s1, q2 = q1;
+        const bool have2 = have1 && step(st1, s1, q1, st2, s2, q2);
+        const symj_u64 m2 = have2 ? jmask[((size_t)st2.w + q2) * 64 + lane] : 0ull;
+        double xj1 = 0.0, xi1 = 0.0;
+        if (have1) {
+            request(m1, jvoff[(size_t)st1.w + q1]);
+            xj1 = x[64 * (st1.y + q1) + lane];
+            if (s1 != s) xi1 = x[64 * st1.x + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (kmax > 0) {                                                // the row, as the dense tiles add it (x_J by readlane: no LDS broadcasts)
+            if (MODE == 0) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) ra += T[lane * SYM_LD + c] * symj_lane(xj_l, c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) {
+                    const double mc = symj_lane(xj_l, c);
+                    const double ig = ineg_of(T[lane * SYM_LD + c], xi_l, mc, Vd);
+                    if (!(diag && c == lane)) { ra += ig * mc; rb += ig; }
+                }
+            }
+        }
+        if (!diag) {
+            double ca = 0.0, cb = 0.0;
+            if (kmax > 0) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 64; ++r) ca += T[r * SYM_LD + lane] * symj_lane(xi_l, r);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 64; ++r) {
+                        const double mi = symj_lane(xi_l, r);
+                        const double ig = ineg_of(T[r * SYM_LD + lane], xj_l, mi, Vd);
+                        ca += ig * mi;
+                        cb += ig;
+                    }
+                }
+            }
+            if (MODE == 0) colpart[t * 64 + lane] = ca;
+            else { colpart[t * 128 + lane] = ca; colpart[t * 128 + 64 + lane] = cb; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (kmax > 0) {   // entries out again: the lane's row (64 plain stores; walking the mask again costs ten instructions per entry)
+#pragma unroll
+            for (int c = 0; c < 64; ++c) T[lane * SYM_LD + c] = 0.0;
+        }
+        if (!more) {                                   // the strip's row parts
+            if (MODE == 0) rowpart[(size_t)s * 64 + lane] = ra;
+            else { rowpart[(size_t)s * 128 + lane] = ra; rowpart[(size_t)s * 128 + 64 + lane] = rb; }
+            ra = rb = 0.0;
+        }
+        if (!have1) break;
+        xjn = xj1;
+        if (s1 != s) {
+            __builtin_amdgcn_wave_barrier();
+            xI[lane] = xi1;
+        }
+        st = st1; s = s1; q = q1; m0 = m1;
+        st1 = st2; s1 = s2; q1 = q2; m1 = m2; have1 = have2;
     }
 }
 
@@ -882,7 +1147,8 @@ extern "C" int kmcf_tstate_destroy(kmcf_tstate *t)
                         t->d_cls_col, t->d_col_node, t->d_diag_pos, t->d_ground, t->d_inv_perm, t->d_diag, t->d_diag_tot, t->d_rhs,
                         t->d_tflag, t->d_blk, t->d_tidx, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->d_rowcnt, t->d_tdiag,
                         t->sub.d_rows, t->sub.d_mask, t->sub.d_voff, t->sub.d_val, t->sub.d_xsub, t->d_pdisp, t->d_scal, t->d_err,
-                        t->sub.d_tiles, t->sub.d_strips, t->sub.d_strip_first, t->sub.d_rowpart, t->sub.d_colpart};
+                        t->sub.d_tiles, t->sub.d_strips, t->sub.d_strip_first, t->sub.d_rowpart, t->sub.d_colpart,
+                        t->sub.d_jmask, t->sub.d_jvoff, t->sub.d_jval, t->sub.d_jcnt};
         for (void *p : ptrs)
             if (p) hipFree(p);
         if (t->h_pin) hipHostFree(t->h_pin);
@@ -1054,8 +1320,9 @@ extern "C" int kmcf_tstate_info(const kmcf_tstate *t, kmcf_tstate_info_t *info)
     info->tunnel_points_rank = t->assembled ? t->sub.n_loc : 0;
     info->tunnel_first = t->assembled ? t->sub.row0 : 0;
     info->nnz_tunnel = t->assembled ? t->sub.nnz : 0;
-    info->tunnel_dense = t->assembled && t->sub.dense ? 1 : 0;
+    info->tunnel_dense = t->assembled && t->sub.dense ? (t->sub.jagged ? 2 : 1) : 0;
     info->tunnel_bytes = !t->assembled ? 0
+                         : t->sub.jagged ? (int64_t)t->sub.jnnz * 8 + (int64_t)t->sub.n_tiles * 520
                          : t->sub.dense ? (int64_t)t->sub.n_tiles * 4096 * 8
                                         : (int64_t)t->sub.nnz * 8 + (int64_t)t->sub.n_loc * ((t->sub.n_glob + 63) / 64) * 8;
     return KMCF_OK;
@@ -1080,16 +1347,20 @@ extern "C" int kmcf_tstate_atom_sites(const kmcf_tstate *t, int *h_atom_site)
 
 // launches of the dense symmetric operator (dynamic LDS beyond 64 KB needs the attribute once per kernel)
 template <int MODE>
-static int symm_launch(kmcf_subop &sb, const double *x, double Vd, hipStream_t st)
+static int symm_launch(kmcf_subop &sb, const double *x, double Vd, hipStream_t st, const kmcf_scalars *S = nullptr, int check_done = 0)
 {
-    static bool attr_done = false;
+    // (the attribute is set per launch: it is per device, and in-process groups launch from several host threads)
     const size_t lds = (size_t)4 * SYM_WAVE_DOUBLES * sizeof(double);
-    if (!attr_done) {
-        KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sub_symm_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));
-    sub_symm_kernel<MODE><<<grid, KMCF_BLOCK, lds, st>>>(sb.n_strips, sb.d_strips, sb.d_tiles, x, Vd, sb.d_rowpart, sb.d_colpart);
+    if (sb.jagged) {
+        KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sub_symj_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        sub_symj_kernel<MODE><<<grid, KMCF_BLOCK, lds, st>>>(sb.n_strips, sb.d_strips, sb.d_jmask, sb.d_jvoff, sb.d_jval, x, Vd, sb.d_rowpart, sb.d_colpart,
+                                                             S, check_done);
+        KMCF_HIP(hipGetLastError());
+        return KMCF_OK;
+    }
+    KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sub_symm_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    sub_symm_kernel<MODE><<<grid, KMCF_BLOCK, lds, st>>>(sb.n_strips, sb.d_strips, sb.d_tiles, x, Vd, sb.d_rowpart, sb.d_colpart, S, check_done);
     KMCF_HIP(hipGetLastError());
     return KMCF_OK;
 }
@@ -1115,7 +1386,7 @@ static int symm_setup(kmcf_tstate *t)
     first[nb] = (int)strips.size();
     KMCF_CHECK(sb.n_tiles < (long long)INT32_MAX, KMCF_ERR_ARG, "tunnel block of %d points: tile index exceeds int32", n_t);
     sb.n_strips = (int)strips.size();
-    KMCF_TRY(ensure(&sb.d_tiles, &sb.cap_tiles, (size_t)sb.n_tiles * 4096));
+    if (!sb.jagged) KMCF_TRY(ensure(&sb.d_tiles, &sb.cap_tiles, (size_t)sb.n_tiles * 4096));
     KMCF_TRY(ensure(&sb.d_strips, &sb.cap_strips, strips.size()));
     KMCF_TRY(ensure(&sb.d_strip_first, &sb.cap_sf, first.size()));
     KMCF_TRY(ensure(&sb.d_rowpart, &sb.cap_rowpart, (size_t)sb.n_strips * 128));
@@ -1124,8 +1395,25 @@ static int symm_setup(kmcf_tstate *t)
     KMCF_HIP(hipMemcpyAsync(sb.d_strip_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
     KMCF_HIP(hipStreamSynchronize(st));                            // (the host vectors go out of scope)
     const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));
-    tunnel_dense_fill_kernel<<<grid, KMCF_BLOCK, 0, st>>>(sb.n_strips, sb.d_strips, n_t, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist,
-                                                         p->tol, p->m_e, p->V0, sb.d_tiles);
+    if (sb.jagged) {
+        // masks tile-major, entries per tile -> first value of every tile -> values in layer order
+        KMCF_TRY(ensure(&sb.d_jmask, &sb.cap_jmask, (size_t)sb.n_tiles * 64));
+        KMCF_TRY(ensure(&sb.d_jcnt, &sb.cap_jcnt, (size_t)sb.n_tiles + 1));
+        KMCF_TRY(ensure(&sb.d_jvoff, &sb.cap_jvoff, (size_t)sb.n_tiles + 2));
+        symj_mask_kernel<<<grid, KMCF_BLOCK, 0, st>>>(sb.n_strips, sb.d_strips, n_t, sb.n_groups, sb.d_mask, sb.d_jmask, sb.d_jcnt);
+        long long *pin_j = reinterpret_cast<long long *>(t->h_pin + 6);
+        scan_exclusive_kernel<long long><<<1, KMCF_BLOCK, 0, st>>>((int)sb.n_tiles, sb.d_jcnt, sb.d_jvoff, nullptr);
+        KMCF_HIP(hipGetLastError());
+        KMCF_HIP(hipMemcpyAsync(pin_j, sb.d_jvoff + sb.n_tiles, sizeof(long long), hipMemcpyDeviceToHost, st));
+        KMCF_HIP(hipStreamSynchronize(st));
+        sb.jnnz = *pin_j;
+        KMCF_TRY(ensure(&sb.d_jval, &sb.cap_jval, (size_t)sb.jnnz + 64));
+        symj_fill_kernel<<<grid, KMCF_BLOCK, 0, st>>>(sb.n_strips, sb.d_strips, n_t, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, p->tol, p->m_e,
+                                                     p->V0, sb.d_jmask, sb.d_jvoff, sb.d_jval);
+    } else {
+        tunnel_dense_fill_kernel<<<grid, KMCF_BLOCK, 0, st>>>(sb.n_strips, sb.d_strips, n_t, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist,
+                                                             p->tol, p->m_e, p->V0, sb.d_tiles);
+    }
     KMCF_HIP(hipGetLastError());
     // diagonal = -(row sums): one application to the vector of ones (the diagonal entries are still 0)
     fill_kernel<<<grid1d(64 * nb), KMCF_BLOCK, 0, st>>>(64 * nb, sb.d_xsub, 1.0);
@@ -1133,7 +1421,8 @@ static int symm_setup(kmcf_tstate *t)
     KMCF_TRY(symm_launch<0>(sb, sb.d_xsub, 0.0, st));
     sub_symm_reduce_kernel<0, false><<<nb, KMCF_BLOCK, 0, st>>>(n_t, nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart, nullptr, nullptr,
                                                                         t->d_tdiag, nullptr, nullptr, nullptr, 0);
-    symm_set_diag_kernel<<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_tiles);
+    if (sb.jagged) symj_set_diag_kernel<<<std::max(1, (nb + 3) / 4), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_jmask, sb.d_jvoff, sb.d_jval);
+    else symm_set_diag_kernel<<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_tiles);
     KMCF_HIP(hipMemsetAsync(sb.d_xsub, 0, (size_t)64 * nb * sizeof(double), st));      // the pad behind the last point stays 0
     KMCF_HIP(hipGetLastError());
     sb.grid = nb;                                                   // blocks = partials of the reduce kernel
@@ -1224,14 +1513,23 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
         // form); in time from a quarter on: the tile kernel streams at 5.3 TB/s, the bitmap kernel -- a load of 64 x d
         // values per mask word -- at 2.7 (the reference's contact window at 40 nm, 44 % full: 3.8 against 6.3 ms per
         // application).  Not when the tiles would take more than 60 % of the free device memory.  KMCF_SUB_DENSE=0 / 1 overrides.
-        sb.dense = P == 1 && n_t >= 2048 && 4.0 * (double)sb.nnz > (double)n_t * (double)n_t;
+        // Round 4: the same tiles holding only their ENTRIES (jagged: 4 B per entry of the full block + 1 bit per position,
+        // the same sums bit for bit, 2.2 x less memory at 44 % -- but bound by its instruction count, not its bytes: the
+        // reference's window on the 4 x 4-cell device, 17 722 points, 44 % full: dense tiles 0.28, jagged tiles 0.41,
+        // bitmap 0.49 ms per iteration) where the dense tiles do not fit the device's memory.
+        // KMCF_SUB_DENSE = 0 bitmap / 1 dense tiles / 2 jagged tiles overrides.
+        const double nn2 = (double)n_t * (double)n_t, nbt = nn2 / 8192;
+        sb.dense = P == 1 && n_t >= 2048 && 4.0 * (double)sb.nnz > nn2;
+        sb.jagged = false;
         if (sb.dense && sb.cap_tiles < (size_t)((long long)((n_t + 63) / 64) * ((n_t + 63) / 64 + 1) / 2) * 4096) {
             size_t fr = 0, tot = 0;
-            const double need = 4.0 * (double)n_t * (double)n_t + 1024.0 * ((double)n_t / 64) * ((double)n_t / 64) / 2;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > 0.6 * (double)fr) sb.dense = false;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && 4.0 * nn2 + 1024.0 * nbt > 0.6 * (double)fr) {
+                sb.jagged = 4.0 * (double)sb.nnz + 1544.0 * nbt <= 0.6 * (double)fr + 8.0 * (double)sb.cap_jval;
+                sb.dense = sb.jagged;
+            }
         }
-        if (const char *e = getenv("KMCF_SUB_DENSE")) sb.dense = P == 1 && atoi(e) != 0;
-        if ((n_t + 63) / 64 > KMCF_MAX_PARTIALS) sb.dense = false;       // (one p.Ap partial per block row)
+        if (const char *e = getenv("KMCF_SUB_DENSE")) { sb.dense = P == 1 && atoi(e) != 0; sb.jagged = sb.dense && atoi(e) == 2; }
+        if ((n_t + 63) / 64 > KMCF_MAX_PARTIALS) sb.dense = sb.jagged = false;       // (one p.Ap partial per block row)
         if (sb.dense) {
             KMCF_TRY(symm_setup(t));
         } else {
@@ -1241,7 +1539,7 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
             KMCF_HIP(hipGetLastError());
         }
     } else {
-        sb.dense = false;
+        sb.dense = sb.jagged = false;
     }
     // 4. preconditioner and right-hand side
     if (n_loc > 0) {
@@ -1301,8 +1599,7 @@ int kmcf_subop_finish(kmcf_matrix *m, bool with_dot, bool skip_if_done)
     if (sb->n_loc == 0) return KMCF_OK;
     double *part = m->d_part_a + 3 * KMCF_MAX_PARTIALS;
     if (sb->dense) {
-        // (skip_if_done: the tile pass is not skipped -- it has no side effect -- the reduce kernel, which adds into Ap, is)
-        KMCF_TRY(symm_launch<0>(*sb, sb->d_xsub, 0.0, st));
+        KMCF_TRY(symm_launch<0>(*sb, sb->d_xsub, 0.0, st, m->d_S, chk));       // (behind the stop: neither pass runs)
         if (with_dot)
             sub_symm_reduce_kernel<0, true><<<sb->grid, KMCF_BLOCK, 0, st>>>(sb->n_glob, sb->nb, sb->d_strip_first, sb->d_rowpart, sb->d_colpart,
                                                                             sb->d_rows, m->d_p, m->d_Ap, nullptr, part, m->d_S, chk);
@@ -1370,7 +1667,29 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
     const int ns = sb.n_loc, ng = sb.n_groups;
     if (h_diag && ns) KMCF_HIP(hipMemcpy(h_diag, t->d_tdiag, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> tiles;
-    if (h_val && sb.nnz && sb.dense) {                       // values out of the upper tiles (test-sized blocks)
+    if (h_val && sb.nnz && sb.jagged) {                      // the same out of the layers of the jagged tiles
+        tiles.assign((size_t)sb.n_tiles * 4096, 0.0);
+        std::vector<unsigned long long> jm((size_t)sb.n_tiles * 64);
+        std::vector<long long> jo((size_t)sb.n_tiles + 1);
+        std::vector<double> jv((size_t)sb.jnnz + 1);
+        KMCF_HIP(hipMemcpy(jm.data(), sb.d_jmask, jm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        KMCF_HIP(hipMemcpy(jo.data(), sb.d_jvoff, jo.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        if (sb.jnnz) KMCF_HIP(hipMemcpy(jv.data(), sb.d_jval, (size_t)sb.jnnz * sizeof(double), hipMemcpyDeviceToHost));
+        for (long long tl = 0; tl < sb.n_tiles; ++tl) {
+            unsigned long long m[64];
+            for (int r = 0; r < 64; ++r) m[r] = jm[(size_t)tl * 64 + r];
+            long long pos = jo[(size_t)tl];
+            for (bool any = true; any;) {                    // layer by layer, rows ascending
+                any = false;
+                for (int r = 0; r < 64; ++r)
+                    if (m[r]) {
+                        tiles[(size_t)tl * 4096 + (size_t)r * 64 + __builtin_ctzll(m[r])] = jv[(size_t)pos++];
+                        m[r] &= m[r] - 1;
+                        any = true;
+                    }
+            }
+        }
+    } else if (h_val && sb.nnz && sb.dense) {                // values out of the upper tiles (test-sized blocks)
         tiles.resize((size_t)sb.n_tiles * 4096);
         KMCF_HIP(hipMemcpy(tiles.data(), sb.d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost));
     } else if (h_val && sb.nnz) {

@@ -412,7 +412,7 @@ def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5
         lattice, sigma, kk, nmet = d["lattice"], d["sigma"], d["k"], len(d["metals"])
     N = len(element)
     res = {}
-    for dense in (0, 1):
+    for dense in (0, 1, 2):                  # bitmap + packed values | dense symmetric tiles | jagged symmetric tiles (entries only)
         monkeypatch.setenv("KMCF_SUB_DENSE", str(dense))
         comm = S.KMC_comm(N, N, N, N)
         comm.connect()
@@ -426,6 +426,7 @@ def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5
         S.t_assemble(buf, prm)
         tn, v = S.t_tunnel(buf), S.t_vectors(buf)
         n = S.t_info(buf)["Nsub"]
+        assert S.t_info(buf)["tunnel_dense"] == dense
         mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
         rng = np.random.default_rng(5)
         x = rng.standard_normal(n)
@@ -465,3 +466,13 @@ def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5
     assert np.abs(a["m"][metal] - b["m"][metal]).max() <= 1e-6 * np.abs(a["m"]).max()
     assert np.abs(a["pw"] - b["pw"]).max() <= 1e-5 * np.abs(a["pw"]).max() + 1e-300
     np.testing.assert_array_equal(a["pw"] == 0, b["pw"] == 0)
+    # the jagged tiles hold the dense tiles' entries and add them in the same order (an absent entry added 0.0 there):
+    # everything identical, bit for bit -- values, diagonal, product, iterates, current, power
+    c = res[2]
+    for key in ("val", "diag", "row_ptr", "col"):
+        np.testing.assert_array_equal(c["tn"][key], b["tn"][key])
+    np.testing.assert_array_equal(c["dinv"], b["dinv"])
+    np.testing.assert_array_equal(c["Ap"], b["Ap"])
+    assert c["st"]["iterations"] == b["st"]["iterations"] and c["im"] == b["im"]
+    np.testing.assert_array_equal(c["m"], b["m"])
+    np.testing.assert_array_equal(c["pw"], b["pw"])

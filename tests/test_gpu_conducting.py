@@ -10,9 +10,9 @@ run never executes the current solver); what is held are relations the device's 
 * the current flows in, and the injection-side sum the reference prints (get_imacro_sparse,
   src/current_solver_gpu.cu:501-542) equals the loop-side current loop_G (Vd - (m[1] - m[0])) to 1e-6 relative at the
   tolerance 1e-15 N, 1e-8 at 1e-18 N (they differ by the source node's residual);
-* the implementations of the same operator agree on it: tunnel block as jagged symmetric tiles (entries only; the
-  default at this density) / dense symmetric tiles / bitmap + packed values, conduction-band edge from the PCG form / from the reference's literally scaled form
-  (solve_sparse_CG_Jacobi, src/iterative_solvers_gpu.cu:716-887) -- to 1e-8 relative at 1e-18 N (measured 5e-10 ...
+* the implementations of the same operator agree on it: tunnel block as dense symmetric tiles (the default at this
+  density) / jagged symmetric tiles (entries only: identical sums) / bitmap + packed values, conduction-band edge from
+  the PCG form / from the reference's literally scaled form (solve_sparse_CG_Jacobi, src/iterative_solvers_gpu.cu:716-887) -- to 1e-8 relative at 1e-18 N (measured 5e-10 ...
   2e-9: different summation orders under a stopping rule that bounds the current's error by 2.4e-7 of it);
 * it responds to the element state: the same device without the filament carries 0.55 % less."""
 import os
@@ -101,15 +101,15 @@ def test_conducting_crossbar_current_is_a_property_of_the_device(km):
         assert np.all(pw[metal] == 0) and np.all(pw >= 0) and pw.max() > 0
         # tight solves: the same current from every implementation of the operator
         res = {}
-        for name, kw in (("tiles", dict(dense="2")), ("dense tiles", dict(dense="1")), ("bitmap", dict(dense="0")),
-                         ("tiles, CB edge scaled form", dict(dense="2", cb_scaled="1"))):
+        for name, kw in (("tiles", dict(dense="1")), ("jagged tiles", dict(dense="2")), ("bitmap", dict(dense="0")),
+                         ("tiles, CB edge scaled form", dict(dense="1", cb_scaled="1"))):
             i2, l2, s2, inf2, b2 = _current(dev, 1e-18, **kw)
             assert s2["converged"] == 1 and int(inf2["tunnel_dense"]) == int(kw["dense"])
             assert abs(i2 - l2) <= max(b2 * 1.01, 1e-25) and abs(i2 - l2) <= 1e-8 * i2, (name, i2, l2, b2)
             res[name] = i2
             print("  %-28s tol 1e-18 N: %d iterations, %.1f ms (%.3f ms per iteration, %.2f GB per application), I_macro %.12e (loop side %.12e)"
                   % (name, s2["iterations"], s2["ms_solve"], s2["ms_solve"] / s2["iterations"], inf2["tunnel_bytes"] * 1e-9, i2, l2))
-        assert res["dense tiles"] == res["tiles"]                                    # (the same sums: tests/test_gpu_tpath.py)
+        assert res["jagged tiles"] == res["tiles"]                                    # (the same sums: tests/test_gpu_tpath.py)
         for name, v in res.items():
             assert abs(v - res["tiles"]) <= 1e-8 * res["tiles"], (name, v, res["tiles"])
         assert abs(res["tiles"] - im) <= 1e-5 * im                                   # (and the looser solve found the same current)

@@ -76,7 +76,32 @@ struct cgr_args {
     long long timeout;
     int limit, check_tol;
     double tol2;
+    // groups of ranks (peer-to-peer transport; kmcf_p2p_dev.hpp): nranks == 1 -> everything below unused
+    int nranks, rank, n_loc;
+    const int *put_row, *putr_ptr;             // per internal row: its entry list (-1: not sent) | entries of a sent row
+    u64 *const *putr_ll;                       // per entry: the granule (parity 0) of that row's value in the RECEIVER's zone
+    const long long *putr_ll_stride;           // ... and the 8-byte words to its parity 1
+    const u64 *halo_ll;                        // my granule zone: halo slot h, parity p at [p * halo_stride + 2 h]
+    long long halo_stride;
+    u64 *const *red_peer;                      // per rank: its reduction zone; mine: red_mine ([2][P2P_MAXR][P2P_FS] words)
+    const u64 *red_mine;
 };
+
+// the same granules with system-scope accesses: a peer's device writes / reads them (fine-grained window memory)
+__device__ __forceinline__ void ll_store_sys(u64 *p, double v, unsigned int seq)
+{
+    const u64 b = (u64)__double_as_longlong(v), s = (u64)seq << 32;
+    __hip_atomic_store(p, (b & 0xffffffffull) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, (b >> 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool ll_try_sys(const u64 *p, unsigned int seq, double &v)
+{
+    const u64 a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)(a >> 32) != seq || (unsigned int)(b >> 32) != seq) return false;
+    v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+    return true;
+}
+
 
 __device__ __forceinline__ u64 cgr_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cgr_st(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -184,10 +209,17 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                                            __builtin_amdgcn_make_buffer_rsrc(A.zll + A.zwords, 0, (int)(A.zwords * 8), 0x00020000)};
     const __amdgpu_buffer_rsrc_t srs[2] = {__builtin_amdgcn_make_buffer_rsrc(A.slot, 0, A.nblocks * 128, 0x00020000),
                                            __builtin_amdgcn_make_buffer_rsrc(A.slot + (size_t)A.nblocks * CGR_LINE, 0, A.nblocks * 128, 0x00020000)};
+    const bool multi = A.nranks > 1;
+    int put0 = 0, put1 = 0;                        // this row's entries in the put table (a row a neighbour rank needs)
+    if (multi && has_row) {
+        const int pr = A.put_row[row];
+        if (pr >= 0) { put0 = A.putr_ptr[pr]; put1 = A.putr_ptr[pr + 1]; }
+    }
     auto publish = [&](double v) {
         if (has_row) {
             if (seq & 1) ll_store16(zrs[1], 16u * (unsigned int)row, v, seq);
             else ll_store16(zrs[0], 16u * (unsigned int)row, v, seq);
+            for (int e = put0; e < put1; ++e) ll_store_sys(A.putr_ll[e] + (seq & 1) * A.putr_ll_stride[e], v, seq);
         }
     };
     // y_row = sum of the row's products with version `seq` of the vector whose own entry is `own`
@@ -203,10 +235,26 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
 #pragma unroll
             for (int q = 0; q < CGR_WQ; ++q)
                 if (need[q]) {
-                    if (ll_try16(zb, 16u * (unsigned int)wc[q], seq, g[q])) need[q] = false;
+                    bool got;
+                    if (multi && wc[q] >= A.n_loc) got = ll_try_sys(A.halo_ll + (seq & 1) * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc), seq, g[q]);
+                    else got = ll_try16(zb, 16u * (unsigned int)wc[q], seq, g[q]);
+                    if (got) need[q] = false;
                     else all = false;
                 }
-            if (all || W.give_up(11)) break;
+            if (all) break;
+            if (W.give_up(11)) {
+#ifdef KMCF_CGR_DEBUG
+                for (int q = 0; q < CGR_WQ; ++q)
+                    if (need[q] && (tid & 63) == __ffsll((long long)__ballot(need[q])) - 1) {
+                        const bool hal = multi && wc[q] >= A.n_loc;
+                        const u64 *pp = hal ? A.halo_ll + (seq & 1) * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc) : A.zll + (size_t)(seq & 1) * A.zwords + 2 * (size_t)wc[q];
+                        printf("cgr gather timeout: rank %d block %d tid %d seq %u col %d (%s, n_loc %d) words %llx %llx\n", A.rank, (int)blockIdx.x, tid, seq, wc[q],
+                               hal ? "halo" : "own", A.n_loc, (unsigned long long)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                               (unsigned long long)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    }
+#endif
+                break;
+            }
             asm volatile("" ::: "memory");                 // (the next pass loads again)
         }
         CGR_T(tp_gather);
@@ -238,7 +286,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     };
     // sums over all rows of up to CGR_NV per-lane values, number `rs`; the same value in every thread of every block
     // (returns false -- in every thread of the block alike -- when a wait of this block has given up)
-    auto reduce = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV], unsigned int rs) -> bool {
+    auto reduce_rank = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV], unsigned int rs) -> bool {
         CGR_T0();
         v0 = kmcf_wave_sum64(v0); v1 = kmcf_wave_sum64(v1);
         if (nv > 2) v2 = kmcf_wave_sum64(v2);
@@ -334,6 +382,44 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         out[0] = bc[0]; out[1] = bc[1]; out[2] = bc[2];
         __syncthreads();                                   // (red / bc are written again by the next reduction)
         return bad == 0;
+    };
+
+    // ... and over the ranks of a group: this rank's sums (the same in every block) go to a line per rank in every peer's
+    // reduction zone; every block adds the P lines of its own zone, one lane per rank (butterfly): the same numbers in the
+    // same order on every rank
+    auto reduce = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV], unsigned int rs) -> bool {
+        const bool ok = reduce_rank(nv, v0, v1, v2, out, rs);
+        if (!multi) return ok;
+        const size_t par = rs & 1;
+        if (blockIdx.x == 0 && gw == 0 && lane < A.nranks) {
+            u64 *dst = A.red_peer[lane] + (par * P2P_MAXR + A.rank) * P2P_FS;
+            ll_store_sys(dst, out[0], rs);
+            ll_store_sys(dst + 2, out[1], rs);
+            if (nv > 2) ll_store_sys(dst + 4, out[2], rs);
+        }
+        if (gw == 1) {
+            const bool mine = lane < A.nranks;
+            const u64 *src = A.red_mine + (par * P2P_MAXR + (mine ? lane : 0)) * P2P_FS;
+            double g[CGR_NV] = {0.0, 0.0, 0.0};
+            bool need[CGR_NV] = {mine, mine, mine && nv > 2};
+            while (true) {
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < CGR_NV; ++i)
+                    if (need[i]) {
+                        if (ll_try_sys(src + 2 * i, rs, g[i])) need[i] = false;
+                        else all = false;
+                    }
+                if (all || W.give_up(14)) break;
+            }
+            g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
+            if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);
+            if (lane == 0) { bc[0] = g[0]; bc[1] = g[1]; bc[2] = g[2]; }
+        }
+        const int bad = __syncthreads_or(W.failed ? 1 : 0);
+        out[0] = bc[0]; out[1] = bc[1]; out[2] = bc[2];
+        __syncthreads();
+        return ok && bad == 0;
     };
 
     // ---- r = b - A x0 ; z = r .* dinv ; gamma = (r, z) ; b.b                 (dist_conjugate_gradient.cpp:178-213)
@@ -478,13 +564,19 @@ static int cgr_plan(kmcf_matrix *m)
     kmcf_cgr *g = new kmcf_cgr();
     m->cgr = g;
     const kmcf_comm *c = m->comm;
-    // one rank, short rows only, no tunnel block, coded row-per-lane stream with lane t = row r0 + t
-    if (c->nranks > 1 || c->force_collectives || m->n_halo > 0 || m->sub || m->n_short != m->n_loc || m->n_loc == 0 || !m->sell_ok || !m->sell_ident ||
-        m->n_sell_tiles <= 0 || m->sell_lw != KMCF_SLOT_BITS)
-        return KMCF_OK;
+    // short rows only, no tunnel block, coded row-per-lane stream with lane t = row r0 + t; one rank, or a group on the
+    // peer-to-peer transport whose every rank qualifies (agreed below)
+    const bool group = c->nranks > 1;
+    bool ok = !(c->force_collectives || m->sub || m->n_short != m->n_loc || m->n_loc == 0 || !m->sell_ok || !m->sell_ident ||
+                m->n_sell_tiles <= 0 || m->sell_lw != KMCF_SLOT_BITS);
+    if (group) ok = ok && c->p2p_active && m->p2p && m->p2p->d_putr_ll && m->n_long_items == 0;
+    else ok = ok && m->n_halo == 0;
+    if (!ok && !group) return KMCF_OK;
     int cus = 0;
     KMCF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    const int share = kmcf_device_share();
+    // (the ranks of an in-process group -- a test device -- share ONE GPU: their launches wait for each other, so all of
+    // them must be resident together)
+    const int share = std::max(kmcf_device_share(), c->group ? c->nranks : 1);
     cgr_args A{};
     int pick = 0;
     const int forced = getenv("KMCF_CGR_TPB") ? atoi(getenv("KMCF_CGR_TPB")) : 0;
@@ -492,7 +584,7 @@ static int cgr_plan(kmcf_matrix *m)
     // more blocks mean more CUs whose LDS pipes share the row sums (measured, us per iteration at 1 / 2 / 4 tiles per
     // block: 5 nm device, 286 tiles: 8.1 / 6.8 / 8.3; a rank's eighth of the 40 nm matrix, 881 tiles: 14.5 / 14.5 / 11.4);
     // beyond 1024 tiles: four per block and the two-hop reduction.
-    for (int pass = 0; pass < 2 && !pick; ++pass)
+    for (int pass = 0; pass < 2 && !pick && ok; ++pass)
         for (int tpb : {1, 2, 4}) {
             if (forced && tpb != forced) continue;
             const int nb = (m->n_sell_tiles + tpb - 1) / tpb;
@@ -502,6 +594,19 @@ static int cgr_plan(kmcf_matrix *m)
             KMCF_TRY(cgr_run_any(m, tpb, A, false, nullptr, &info));
             if (info.per_cu >= 1 && nb <= (long long)info.per_cu * cus / share) { pick = tpb; break; }
         }
+    if (group) {
+        // every rank runs the resident launch or none does (the launches wait for each other): the ranks that could, counted
+        double *d_v = c->d_scratch;
+        const double mine = pick ? 1.0 : 0.0;
+        double all = 0.0;
+        KMCF_HIP(hipMemcpyAsync(d_v, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        KMCF_HIP(hipStreamSynchronize(c->stream));
+        KMCF_TRY(kmcf_comm_allreduce_sum(const_cast<kmcf_comm *>(c), d_v, 1));
+        KMCF_HIP(hipStreamSynchronize(c->stream));
+        KMCF_TRY(kmcf_p2p_check(const_cast<kmcf_comm *>(c)));
+        KMCF_HIP(hipMemcpy(&all, d_v, sizeof(double), hipMemcpyDeviceToHost));
+        if (all != (double)c->nranks) pick = 0;
+    }
     if (!pick) return KMCF_OK;
     g->tpb = pick;
     g->nblocks = (m->n_sell_tiles + pick - 1) / pick;
@@ -523,7 +628,14 @@ static int cgr_plan(kmcf_matrix *m)
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_err), sizeof(int)));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_err), sizeof(int), hipHostMallocDefault));
     *g->h_err = 0;
-    g->seq_bound = 0xffffffffull;                                   // (forces the reset below on first use)
+    // granules never carry sequence number 0: everything starts cleared (the zones in the peer-to-peer window were
+    // cleared when the matrix was built, kmcf_p2p_matrix_alloc)
+    KMCF_HIP(hipMemset(g->d_zll, 0, 2 * g->zwords * sizeof(u64)));
+    KMCF_HIP(hipMemset(g->d_slot, 0, 2 * (size_t)g->nblocks * CGR_LINE * sizeof(u64)));
+    KMCF_HIP(hipMemset(g->d_gslot, 0, 2 * (size_t)g->ngroups * CGR_LINE * sizeof(u64)));
+    KMCF_HIP(hipMemset(g->d_seq, 0, sizeof(unsigned int)));
+    KMCF_HIP(hipMemset(g->d_err, 0, sizeof(int)));
+    g->seq_bound = 0;
     return KMCF_OK;
 }
 
@@ -536,7 +648,8 @@ bool kmcf_cgr_usable(kmcf_matrix *m)
 
 int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks)
 {
-    const bool ok = kmcf_cgr_usable(m);
+    // (a group's plan is agreed among its ranks at the first solve: asking must not start that exchange)
+    const bool ok = (m->comm->nranks > 1 && !m->cgr) ? false : kmcf_cgr_usable(m);
     if (tpb) *tpb = ok ? m->cgr->tpb : 0;
     if (g1) *g1 = ok ? m->cgr->g1 : 0;
     if (nblocks) *nblocks = ok ? m->cgr->nblocks : 0;
@@ -556,11 +669,26 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     // sequence numbers are 32 bits in the LL words and must never repeat within the life of the buffers: well before
     // the counter could wrap, the buffers are cleared and the counter starts again
     if (g->seq_bound + (unsigned long long)limit + 16 > 0xf0000000ull) {
+        // (a group: every rank reaches this point in the same solve -- the bound advances identically -- and clears its
+        // zones between two collectives: nobody still writes granules of the solve before, nobody publishes early)
+        if (c->nranks > 1) {
+            KMCF_HIP(hipStreamSynchronize(st));
+            KMCF_TRY(kmcf_comm_allreduce_sum(c, c->d_scratch, 1));
+            KMCF_HIP(hipStreamSynchronize(st));
+        }
         KMCF_HIP(hipMemsetAsync(g->d_zll, 0, 2 * g->zwords * sizeof(u64), st));
         KMCF_HIP(hipMemsetAsync(g->d_slot, 0, 2 * (size_t)g->nblocks * CGR_LINE * sizeof(u64), st));
         KMCF_HIP(hipMemsetAsync(g->d_gslot, 0, 2 * (size_t)g->ngroups * CGR_LINE * sizeof(u64), st));
         KMCF_HIP(hipMemsetAsync(g->d_seq, 0, sizeof(unsigned int), st));
         KMCF_HIP(hipMemsetAsync(g->d_err, 0, sizeof(int), st));
+        if (c->nranks > 1) {
+            char *win = kmcf_p2p_window(c);
+            KMCF_HIP(hipMemsetAsync(win + m->p2p->ll_off, 0, 2 * (size_t)std::max(m->n_halo, 1) * 2 * sizeof(u64), st));
+            KMCF_HIP(hipMemsetAsync(win + m->p2p->red_off, 0, 2 * (size_t)P2P_MAXR * P2P_FS * sizeof(u64), st));
+            KMCF_HIP(hipStreamSynchronize(st));
+            KMCF_TRY(kmcf_comm_allreduce_sum(c, c->d_scratch, 1));
+            KMCF_HIP(hipStreamSynchronize(st));
+        }
         g->seq_bound = 0;
     }
     g->seq_bound += (unsigned long long)limit + 8;
@@ -578,7 +706,18 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     A.slot = g->d_slot; A.gslot = g->d_gslot; A.seq = g->d_seq;
     A.d_err = g->d_err; A.h_err = g->h_err;
     A.timeout = (long long)rate_khz * timeout_ms;
+    if (c->nranks > 1 && c->p2p && !getenv("KMCF_CGR_TIMEOUT_MS")) A.timeout = c->p2p->timeout_ticks;      // (a group: the transport's bound, KMCF_P2P_TIMEOUT_MS)
     A.limit = limit; A.check_tol = fixed_iters > 0 ? 0 : 1; A.tol2 = tol * tol;
+    A.nranks = c->nranks; A.rank = c->rank; A.n_loc = m->n_loc;
+    if (c->nranks > 1) {
+        const kmcf_p2p_halo *h = m->p2p;
+        char *win = kmcf_p2p_window(c);
+        A.put_row = h->d_put_row; A.putr_ptr = h->d_putr_ptr; A.putr_ll = h->d_putr_ll; A.putr_ll_stride = h->d_putr_ll_stride;
+        A.halo_ll = reinterpret_cast<const u64 *>(win + h->ll_off);
+        A.halo_stride = 2 * (long long)std::max(m->n_halo, 1);
+        A.red_peer = h->d_red_peer;
+        A.red_mine = reinterpret_cast<const u64 *>(win + h->red_off);
+    }
     return cgr_run_any(m, g->tpb, A, true, st, nullptr);
 }
 

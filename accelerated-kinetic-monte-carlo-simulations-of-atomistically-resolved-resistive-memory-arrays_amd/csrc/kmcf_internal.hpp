@@ -417,9 +417,10 @@ int kmcf_p2p_allreduce(kmcf_comm *c, double *d_buf, int count);
 // returns at once (on every rank alike) when skip_if_done and S->done
 int kmcf_p2p_allreduce_parts(kmcf_comm *c, const kmcf_part4 *part, int count, kmcf_scalars *d_S, int skip_if_done);
 int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int *displs, size_t elem, hipStream_t st = nullptr);
-int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8);
+int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8, int *ll_off8, int *red_off8);
 int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8,
-                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo);
+                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo,
+                            const std::vector<long long> &r_ll8, const std::vector<long long> &r_red8);
 void kmcf_p2p_matrix_free(kmcf_matrix *m);
 int kmcf_p2p_halo_exchange(kmcf_matrix *m);
 // "direct" protocol (kmcf_p2p_dev.hpp): usable for this matrix?  (group on the p2p transport, per-row put table built)

@@ -319,11 +319,13 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
     if (P > 1 && c->connected && (c->p2p_active || !c->group)) {
         // per rank: sent to q | expected from q | landing offset | flag offset | acknowledgement offset (8-byte units, in
         // this rank's window, for what q sends) | this rank's halo size (= distance between its two landing buffers)
-        const int W = 6 * P;
+        // | first granule of q's values in this rank's granule zone | this rank's reduction zone (register-resident solve)
+        const int W = 8 * P;
         std::vector<int> tab((size_t)W * P, 0), cnt(P, W), dsp(P);
         for (int q = 0; q < P; ++q) dsp[q] = W * q;
-        int land8 = 0, flag8 = 0, ack8 = 0;
-        if (c->p2p_active) KMCF_TRY(kmcf_p2p_matrix_alloc(m, &land8, &flag8, &ack8));
+        int land8 = 0, flag8 = 0, ack8 = 0, ll8 = 0, red8 = 0;
+        if (c->p2p_active) KMCF_TRY(kmcf_p2p_matrix_alloc(m, &land8, &flag8, &ack8, &ll8, &red8));
+        for (int q = 0; q < P; ++q) tab[(size_t)W * rank + 7 * P + q] = red8;
         for (int k = 1; k < nnb; ++k) {
             const int q = m->neighbours[k];
             tab[(size_t)W * rank + q] = (int)m->rows_per_neighbour[k].size();
@@ -332,6 +334,7 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
             tab[(size_t)W * rank + 3 * P + q] = flag8 + (k - 1) * 16;               // (one 128-byte line per flag: P2P_FS)
             tab[(size_t)W * rank + 4 * P + q] = ack8 + (k - 1) * 16;                // q acknowledges MY puts here
             tab[(size_t)W * rank + 5 * P + q] = std::max(m->n_halo, 1);
+            tab[(size_t)W * rank + 6 * P + q] = ll8 + 2 * m->halo_offset[k];
         }
         // (kept until the matrix is destroyed: hipFree waits for EVERY stream of the process, and in an in-process group
         // another rank's kernel may already be waiting, on the device, for this rank's next exchange)
@@ -365,15 +368,18 @@ int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const in
                            (int)m->cols_per_neighbour.size(), tab[(size_t)W * a + 5 * P + b], tab[(size_t)W * b + 5 * P + a], lst.c_str());
             }
         if (c->p2p_active) {
-            std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0), r_ack((size_t)nnb, 0), r_halo((size_t)nnb, 0);
+            std::vector<long long> r_land((size_t)nnb, 0), r_flag((size_t)nnb, 0), r_ack((size_t)nnb, 0), r_halo((size_t)nnb, 0), r_ll((size_t)nnb, 0);
+            std::vector<long long> r_red((size_t)P, 0);
             for (int k = 1; k < nnb; ++k) {
                 const int q = m->neighbours[k];
                 r_land[k] = tab[(size_t)W * q + 2 * P + rank];
                 r_flag[k] = tab[(size_t)W * q + 3 * P + rank];
                 r_ack[k] = tab[(size_t)W * q + 4 * P + rank];
                 r_halo[k] = tab[(size_t)W * q + 5 * P + rank];
+                r_ll[k] = tab[(size_t)W * q + 6 * P + rank];
             }
-            KMCF_TRY(kmcf_p2p_matrix_connect(m, r_land, r_flag, r_ack, r_halo));
+            for (int q = 0; q < P; ++q) r_red[(size_t)q] = tab[(size_t)W * q + 7 * P + rank];
+            KMCF_TRY(kmcf_p2p_matrix_connect(m, r_land, r_flag, r_ack, r_halo, r_ll, r_red));
         }
     }
     guard.m = nullptr;

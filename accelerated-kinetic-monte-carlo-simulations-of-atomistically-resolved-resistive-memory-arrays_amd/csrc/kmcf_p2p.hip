@@ -405,7 +405,7 @@ int kmcf_p2p_allgatherv(kmcf_comm *c, void *d_buf, const int *counts, const int 
 }
 
 // ---------------------------------------------------------------- halo protocol of one matrix
-int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8)
+int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *ack_off8, int *ll_off8, int *red_off8)
 {
     kmcf_p2p *w = m->comm->p2p;
     kmcf_p2p_halo *h = new kmcf_p2p_halo();
@@ -414,7 +414,11 @@ int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *a
     h->land_off = align_up(w->bump, 256);
     h->flag_off = align_up(h->land_off + 2 * (size_t)std::max(m->n_halo, 1) * sizeof(double), 256);     // two buffers (sequence parity)
     h->ack_off = align_up(h->flag_off + (size_t)std::max(n_nb, 1) * P2P_FS * sizeof(u64), 256);      // (one line per flag)
-    const size_t end = h->ack_off + (size_t)std::max(n_nb, 1) * P2P_FS * sizeof(u64);
+    // granule zone and reduction zone of the register-resident solve (kmcf_cgr.hip): zeroed with the flags -- a granule's
+    // sequence number is never 0
+    h->ll_off = align_up(h->ack_off + (size_t)std::max(n_nb, 1) * P2P_FS * sizeof(u64), 256);
+    h->red_off = align_up(h->ll_off + 2 * (size_t)std::max(m->n_halo, 1) * 2 * sizeof(u64), 256);
+    const size_t end = h->red_off + 2 * (size_t)P2P_MAXR * P2P_FS * sizeof(u64);
     KMCF_CHECK(end <= w->win_bytes, KMCF_ERR_NOMEM, "p2p window exhausted (%zu of %zu bytes; KMCF_P2P_WINDOW_MB)", end, w->win_bytes);
     w->bump = end;
     KMCF_HIP(hipMemset(w->win + h->flag_off, 0, end - h->flag_off));
@@ -423,13 +427,17 @@ int kmcf_p2p_matrix_alloc(kmcf_matrix *m, int *land_off8, int *flag_off8, int *a
     *land_off8 = (int)(h->land_off / 8);
     *flag_off8 = (int)(h->flag_off / 8);
     *ack_off8 = (int)(h->ack_off / 8);
+    *ll_off8 = (int)(h->ll_off / 8);
+    *red_off8 = (int)(h->red_off / 8);
     return KMCF_OK;
 }
 
 // r_land8[k], r_flag8[k], r_ack8[k] (k >= 1): where neighbour k wants MY data / my flag / my acknowledgement of ITS
 // puts inside ITS window (units of 8 bytes); r_halo[k]: its halo size = distance between its two landing buffers
 int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land8, const std::vector<long long> &r_flag8,
-                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo)
+                            const std::vector<long long> &r_ack8, const std::vector<long long> &r_halo,
+                            const std::vector<long long> &r_ll8 /* per neighbour: first granule of MY values in ITS zone */,
+                            const std::vector<long long> &r_red8 /* per RANK: its reduction zone */)
 {
     kmcf_p2p *w = m->comm->p2p;
     kmcf_p2p_halo *h = m->p2p;
@@ -437,12 +445,15 @@ int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land
     std::vector<double *> put((size_t)std::max(m->n_send, 1), nullptr);
     std::vector<long long> stride((size_t)std::max(m->n_send, 1), 0);
     std::vector<u64 *> flg((size_t)std::max(nnb - 1, 1), nullptr), ack((size_t)std::max(nnb - 1, 1), nullptr);
+    std::vector<u64 *> put_ll((size_t)std::max(m->n_send, 1), nullptr);
     for (int k = 1; k < nnb; ++k) {
         char *base = w->peer[m->neighbours[k]];
         double *land = reinterpret_cast<double *>(base) + r_land8[k];
+        u64 *ll = reinterpret_cast<u64 *>(base) + r_ll8[k];
         for (size_t i = 0; i < m->rows_per_neighbour[k].size(); ++i) {
             put[(size_t)m->send_offset[k] + i] = land + i;
             stride[(size_t)m->send_offset[k] + i] = r_halo[k];
+            put_ll[(size_t)m->send_offset[k] + i] = ll + 2 * i;
         }
         flg[(size_t)k - 1] = reinterpret_cast<u64 *>(base) + r_flag8[k];
         ack[(size_t)k - 1] = reinterpret_cast<u64 *>(base) + r_ack8[k];
@@ -466,14 +477,26 @@ int kmcf_p2p_matrix_connect(kmcf_matrix *m, const std::vector<long long> &r_land
                 per_row[(size_t)inv[m->rows_per_neighbour[k][i]]].push_back(m->send_offset[k] + (int)i);
         std::vector<int> put_row((size_t)std::max(n, 1), -1), rptr(1, 0);
         std::vector<double *> raddr;
-        std::vector<long long> rstride;
+        std::vector<long long> rstride, rllstride;
+        std::vector<u64 *> rll;
         for (int i = 0; i < n; ++i) {
             if (per_row[i].empty()) continue;
             put_row[i] = (int)rptr.size() - 1;
-            for (int e : per_row[i]) { raddr.push_back(put[(size_t)e]); rstride.push_back(stride[(size_t)e]); }
+            for (int e : per_row[i]) {
+                raddr.push_back(put[(size_t)e]); rstride.push_back(stride[(size_t)e]);
+                rll.push_back(put_ll[(size_t)e]); rllstride.push_back(2 * stride[(size_t)e]);
+            }
             rptr.push_back((int)raddr.size());
         }
-        if (raddr.empty()) { raddr.push_back(nullptr); rstride.push_back(0); }
+        if (raddr.empty()) { raddr.push_back(nullptr); rstride.push_back(0); rll.push_back(nullptr); rllstride.push_back(0); }
+        std::vector<u64 *> redp((size_t)m->comm->nranks, nullptr);
+        for (int q = 0; q < m->comm->nranks; ++q) redp[(size_t)q] = reinterpret_cast<u64 *>(w->peer[q]) + r_red8[(size_t)q];
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_ll), rll.size() * sizeof(u64 *)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_ll_stride), rllstride.size() * sizeof(long long)));
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_red_peer), redp.size() * sizeof(u64 *)));
+        KMCF_HIP(hipMemcpy(h->d_putr_ll, rll.data(), rll.size() * sizeof(u64 *), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(h->d_putr_ll_stride, rllstride.data(), rllstride.size() * sizeof(long long), hipMemcpyHostToDevice));
+        KMCF_HIP(hipMemcpy(h->d_red_peer, redp.data(), redp.size() * sizeof(u64 *), hipMemcpyHostToDevice));
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_put_row), put_row.size() * sizeof(int)));
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_ptr), rptr.size() * sizeof(int)));
         KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_putr_addr), raddr.size() * sizeof(double *)));
@@ -552,6 +575,9 @@ void kmcf_p2p_matrix_free(kmcf_matrix *m)
     if (m->p2p->d_putr_ptr) hipFree(m->p2p->d_putr_ptr);
     if (m->p2p->d_putr_addr) hipFree(m->p2p->d_putr_addr);
     if (m->p2p->d_putr_stride) hipFree(m->p2p->d_putr_stride);
+    if (m->p2p->d_putr_ll) hipFree(m->p2p->d_putr_ll);
+    if (m->p2p->d_putr_ll_stride) hipFree(m->p2p->d_putr_ll_stride);
+    if (m->p2p->d_red_peer) hipFree(m->p2p->d_red_peer);
     if (m->p2p->d_ctr) hipFree(m->p2p->d_ctr);
     delete m->p2p;
     m->p2p = nullptr;

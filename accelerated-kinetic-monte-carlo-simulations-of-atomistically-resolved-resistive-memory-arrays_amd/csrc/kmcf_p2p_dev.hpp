@@ -58,6 +58,13 @@ struct kmcf_p2p_halo {
     int *d_putr_ptr = nullptr;               // per sent row: its entries in d_putr_addr / d_putr_stride (one per receiving neighbour)
     double **d_putr_addr = nullptr;
     long long *d_putr_stride = nullptr;
+    // register-resident solve of a group (kmcf_cgr.hip): the halo travels as 16-byte {value, sequence} granules, written
+    // by the lane that owns the row straight into the receiver's granule zone (two parities of n_halo granules behind
+    // its landing buffers); every rank's sums go to a line per rank in every peer's reduction zone
+    size_t ll_off = 0, red_off = 0;          // own granule zone / reduction zone (2 x P2P_MAXR lines) in my window
+    u64 **d_putr_ll = nullptr;               // per entry of d_putr_addr: the remote granule (parity 0)
+    long long *d_putr_ll_stride = nullptr;   // ... 8-byte words from parity 0 to parity 1 there (2 x the receiver's halo size)
+    u64 **d_red_peer = nullptr;              // per rank: its reduction zone
 };
 
 // What a compute kernel needs to take part in the exchanges itself (by value in the kernel arguments).  "Direct"

@@ -359,6 +359,101 @@ def _order_lib():
     return L
 
 
+def pcg_resident_ranks(ranks, counts, displs, rhs, x0, dinv, tol, max_it, fixed_iters=0):
+    """The single-reduction PCG of a group of ranks as every rank's ONE register-resident launch adds it
+    (csrc/kmcf_cgr.hip, nranks > 1): rows as the row-per-lane kernel adds them over [own | halo], a rank's sums over
+    its tiles / blocks / reduction tree (plan: resident_tpb, resident_g1), the ranks' sums by a butterfly with one lane
+    per rank.  ranks: list of DeviceRank; rhs, x0, dinv: GLOBAL vectors in the caller's order.  Returns dict(x, r
+    (global), iterations, converged, bb, rz)."""
+    L = lib()
+    if not hasattr(L, "_resident_ready"):
+        L.orc_resident_spmv.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L.orc_resident_rank_sum.restype = C.c_double
+        L.orc_resident_rank_sum.argtypes = [C.c_int, _ip, _ip, C.c_int, C.c_int, _dp]
+        L.orc_wave_sum_n.restype = C.c_double
+        L.orc_wave_sum_n.argtypes = [_dp, C.c_int]
+        L._resident_ready = True
+    P = len(ranks)
+    assert all(rk.plan["resident_tpb"] > 0 for rk in ranks), "a rank's plan names no resident launch"
+    tol2 = float(tol) * float(tol)
+    n_glob = int(displs[-1]) + int(counts[-1])
+    S = []
+    for q, rk in enumerate(ranks):
+        sl = slice(int(displs[q]), int(displs[q]) + int(counts[q]))
+        g = lambda v: _f(v)[sl][rk.perm].copy()
+        S.append(dict(b=g(rhs), x=g(x0), di=g(dinv) if dinv is not None else np.ones(rk.n), xv=np.zeros(rk.n + rk.n_halo),
+                      w=np.zeros(rk.n), tf=_i(rk.plan["tile_first"]), tr=_i(rk.plan["tile_rows"])))
+
+    def spmv(key):
+        glob = np.zeros(n_glob)
+        for q, rk in enumerate(ranks):
+            glob[int(displs[q]) + rk.perm] = S[q][key]
+        for q, rk in enumerate(ranks):
+            xv = S[q]["xv"]
+            xv[:rk.n] = S[q][key]
+            if rk.n_halo:
+                xv[rk.n:] = glob[rk.halo_gid]
+            L.orc_resident_spmv(rk.n, rk.rp, rk.col, rk.val, xv, S[q]["w"])
+
+    def total(key):
+        loc = np.zeros(64)
+        for q, rk in enumerate(ranks):
+            loc[q] = L.orc_resident_rank_sum(len(S[q]["tf"]), S[q]["tf"], S[q]["tr"], int(rk.plan["resident_tpb"]),
+                                             int(rk.plan["resident_g1"]), np.ascontiguousarray(S[q][key]))
+        return loc[0] if P == 1 else L.orc_wave_sum_n(loc, P)
+
+    for s_ in S:
+        s_["z"] = s_["x"].copy()
+    spmv("z")
+    for s_ in S:
+        s_["r"] = s_["b"] + (-1.0) * s_["w"]
+        s_["z"] = s_["r"] * s_["di"]
+        s_["gp"] = s_["r"] * s_["z"]
+        s_["bbp"] = s_["b"] * s_["b"]
+        s_["p"] = np.zeros_like(s_["r"])
+        s_["s"] = np.zeros_like(s_["r"])
+    limit = int(fixed_iters) if fixed_iters > 0 else int(max_it)
+    bb = g_old = a_old = rz_last = 0.0
+    iters, done = 0, False
+    for k in range(1, limit + 1):
+        first = k == 1
+        spmv("z")
+        for s_ in S:
+            s_["dp"] = s_["z"] * s_["w"]
+        gamma, delta = total("gp"), total("dp")
+        if first:
+            bb = total("bbp")
+        go = True if fixed_iters > 0 else (gamma / bb > tol2)
+        rz_last = gamma
+        if not go:
+            done = True
+            break
+        if first:
+            beta, alpha = 0.0, gamma / delta
+        else:
+            beta = gamma / g_old
+            alpha = gamma / (delta - beta * gamma / a_old)
+        g_old, a_old = gamma, alpha
+        iters += 1
+        na = -alpha
+        for s_ in S:
+            s_["s"] = s_["w"].copy() if first else s_["w"] + beta * s_["s"]
+            s_["r"] = s_["r"] + na * s_["s"]
+            zn = s_["r"] * s_["di"]
+            s_["p"] = s_["z"].copy() if first else s_["z"] + beta * s_["p"]
+            s_["x"] = s_["x"] + alpha * s_["p"]
+            s_["z"] = zn
+            s_["gp"] = s_["r"] * s_["z"]
+    if not done:
+        rz_last = total("gp")
+    xo, ro = np.zeros(n_glob), np.zeros(n_glob)
+    for q, rk in enumerate(ranks):
+        xo[int(displs[q]) + rk.perm] = S[q]["x"]
+        ro[int(displs[q]) + rk.perm] = S[q]["r"]
+    return dict(x=xo, r=ro, iterations=iters, converged=1 if done else 0, bb=bb, rz=rz_last,
+                relres=float(np.sqrt(rz_last / bb)) if bb > 0 else 0.0)
+
+
 def pcg_device_order_ranks(ranks, counts, displs, rhs, x0, dinv, tol, max_it, fixed_iters=0, variant="classic",
                            sub_counts=None, sub_displs=None, history=False):
     """The reference's Jacobi-PCG over a group of ranks in the device's summation order: every rank's kernels by

@@ -444,6 +444,32 @@ int orc_pcg1_resident_order(int n, const int *rp, const int *col, const double *
     return iters;
 }
 
+/* Pieces of the register-resident solve for groups of ranks (csrc/kmcf_cgr.hip with nranks > 1), driven rank by rank
+ * from kmcf_oracle.py: pcg_resident_ranks.  Row sums over a rank's rows with xv = [own | halo] (every row, boundary
+ * rows included, is added like the row-per-lane kernel adds it); a rank's sum of one value per row over its tiles,
+ * blocks and reduction tree; the butterfly over the ranks' sums (one lane per rank). */
+void orc_resident_spmv(int n, const int *rp, const int *col, const double *val, const double *xv, double *y)
+{
+    for (int i = 0; i < n; ++i) y[i] = row_sum_diag_last(i, rp, col, val, xv);
+}
+
+double orc_resident_rank_sum(int n_tiles, const int *tile_first, const int *tile_rows, int tpb, int g1, const double *row_val)
+{
+    double *lv = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    for (int c = 0; c < n_tiles; ++c)
+        for (int t = 0; t < tile_rows[c]; ++t) lv[(size_t)c * BLK + t] = row_val[tile_first[c] + t];
+    const double r = resident_sum(lv, n_tiles, tpb, g1);
+    free(lv);
+    return r;
+}
+
+double orc_wave_sum_n(const double *v, int n)
+{
+    double a[64];
+    for (int l = 0; l < 64; ++l) a[l] = l < n ? v[l] : 0.0;
+    return wave_sum64(a);
+}
+
 /* y = A x in the row-per-lane kernel's order (for SpMV parity at bit level) */
 void orc_spmv_device_order(int n_tiles, const int *tile_first, const int *tile_rows, int sell_grid, const int *rp,
                            const int *col, const double *val, const double *x, double *y)

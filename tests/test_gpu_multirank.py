@@ -179,6 +179,7 @@ def test_p2p_transport_in_process_matches_loopback_bit_for_bit(km, oracle, dev5,
     loopback transport: same partition, same kernels, so charges, solution, iteration count and events must be
     IDENTICAL, bit for bit (both transports add the ranks' partial dot products in rank order)."""
     monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
+    monkeypatch.setenv("KMCF_CG_RESIDENT", "0")             # (the loop of kernels on both transports; the resident launch: next test)
     monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
     monkeypatch.delenv("KMCF_TRANSPORT", raising=False)
     base = _run_ranks(km, dev5, P, ref5["charge"])
@@ -190,6 +191,42 @@ def test_p2p_transport_in_process_matches_loopback_bit_for_bit(km, oracle, dev5,
         assert a["st"]["iterations"] == b["st"]["iterations"] and a["st"]["relres"] == b["st"]["relres"]
         assert np.array_equal(a["Ap"], b["Ap"]) and np.array_equal(a["v"], b["v"]) and np.array_equal(a["tot2"], b["tot2"])
         assert a["ev_n"] == b["ev_n"] and np.array_equal(a["ev_log"], b["ev_log"]) and a["ev_t"] == b["ev_t"]
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_resident_group_solve_matches_its_oracle_bit_for_bit(km, oracle, dev5, ref5, P, monkeypatch):
+    """A group's solve as ONE register-resident launch per rank (csrc/kmcf_cgr.hip with nranks > 1: the halo as
+    {value, sequence} granules put straight into the receiver's window by the lane that owns the row, every rank's sums
+    to a line per rank in every peer's window), P ranks = P host threads on the peer-to-peer transport: against the oracle
+    adding in exactly that order (kmcf_oracle.pcg_resident_ranks) -- iteration count and every entry of the solution
+    identical -- and against the reference's recurrence through the solution bars.  Charges, gathers and events as on
+    the other transports."""
+    monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
+    monkeypatch.setenv("KMCF_CG_RESIDENT", "1")
+    monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
+    monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+    monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
+    monkeypatch.setenv("KMCF_CGR_TIMEOUT_MS", "20000")
+    out = _run_ranks(km, dev5, P, ref5["charge"], expect_transport="p2p (in-process group)")
+    ks, A = ref5["ks"], ref5["A"]
+    assert all(o["plan"]["cg_variant"] == 1 and o["plan"]["resident_tpb"] > 0 for o in out), [o["plan"]["resident_tpb"] for o in out]
+    counts, displs = oracle.partition(ks.n, P)
+    ranks = [oracle.DeviceRank(o["plan"]) for o in out]
+    rhs = np.concatenate([o["kv"]["rhs"] for o in out])
+    dinv = np.concatenate([o["kv"]["dinv"] for o in out])
+    orc = oracle.pcg_resident_ranks(ranks, counts, displs, rhs, np.zeros(ks.n), dinv, ref5["tol"], 10000)
+    its = {o["st"]["iterations"] for o in out}
+    assert its == {orc["iterations"]}, (its, orc["iterations"])
+    NL = dev5["N_contact"]
+    for o in out:
+        assert np.array_equal(o["charge"], ref5["charge"])
+        assert o["st"]["converged"] == 1 and o["st"]["rz"] == orc["rz"] and o["st"]["bb"] == orc["bb"]
+        np.testing.assert_array_equal(o["v"][NL:NL + ks.n], orc["x"])            # replicated by sum_and_gather, identical to the oracle
+    dx = np.abs(orc["x"] - ref5["x"])
+    assert dx.max() <= 5e-4 and np.median(dx) <= 5e-6
+    assert abs(orc["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"]
+    res = A["rhs"] - oracle.spmv(ks.row_ptr, ks.col, A["val"], orc["x"])
+    assert np.linalg.norm(res) / np.linalg.norm(A["rhs"]) <= TRUE_RESIDUAL_BAR
 
 
 @pytest.mark.parametrize("n,P", [(10, 4), (3, 4), (2000, 3)])
@@ -258,6 +295,7 @@ def test_p2p_slow_rank_cannot_have_its_halo_overwritten(km, oracle, dev5, ref5, 
     monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
     monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
     monkeypatch.delenv("KMCF_TRANSPORT", raising=False)
+    monkeypatch.setenv("KMCF_CG_RESIDENT", "0")             # (this test is about the halo protocol of the kernel loop)
     base = _run_ranks(km, dev5, 3, ref5["charge"])
     monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
     monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")

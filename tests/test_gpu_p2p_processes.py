@@ -31,7 +31,8 @@ def test_ranks_as_processes_over_ipc_windows(km, oracle, dev5, ref5, tmp_path, P
     procs = []
     for r in range(P):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(P), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", KMCF_P2P_TIMEOUT_MS="20000")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", KMCF_P2P_TIMEOUT_MS="20000",
+                   KMCF_DEVICE_SHARE=str(P))      # (the P processes share the box's one GPU: grids that must be resident together take 1/P of it)
         env.pop("KMCF_TRANSPORT", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

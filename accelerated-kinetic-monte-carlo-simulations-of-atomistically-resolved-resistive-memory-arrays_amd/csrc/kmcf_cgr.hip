@@ -568,7 +568,7 @@ static int cgr_plan(kmcf_matrix *m)
     // peer-to-peer transport whose every rank qualifies (agreed below)
     const bool group = c->nranks > 1;
     bool ok = !(c->force_collectives || m->sub || m->n_short != m->n_loc || m->n_loc == 0 || !m->sell_ok || !m->sell_ident ||
-                m->n_sell_tiles <= 0 || m->sell_lw != KMCF_SLOT_BITS);
+                m->n_sell_tiles <= 0 || m->sell_lw != KMCF_SLOT_BITS || !kmcf_sell_coded_active(m));
     if (group) ok = ok && c->p2p_active && m->p2p && m->p2p->d_putr_ll && m->n_long_items == 0;
     else ok = ok && m->n_halo == 0;
     if (!ok && !group) return KMCF_OK;
@@ -641,7 +641,10 @@ static int cgr_plan(kmcf_matrix *m)
 
 bool kmcf_cgr_usable(kmcf_matrix *m)
 {
-    if (cgr_mode() == 0 || !kmcf_sell_coded_active(m)) return false;
+    if (cgr_mode() == 0) return false;
+    // a group agrees on the launch inside cgr_plan (a collective): every rank must get there or none -- so what decides
+    // here is the same on every rank (the transport); what differs from rank to rank is weighed inside
+    if (m->comm->nranks > 1 ? !m->comm->p2p_active : !kmcf_sell_coded_active(m)) return false;
     if (cgr_plan(m) != KMCF_OK) return false;
     return m->cgr && m->cgr->tpb > 0;
 }

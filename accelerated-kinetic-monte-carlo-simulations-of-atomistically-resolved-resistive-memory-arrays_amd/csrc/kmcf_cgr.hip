@@ -24,8 +24,9 @@
 // Reduction: every block publishes its sums in a 128-byte line of its own; the leader of each group of g1 blocks adds
 // its group (one lane per block, wavefront butterfly) and publishes the group's sums; every block adds the group sums
 // (one lane per group, butterfly).  No read-modify-write on a shared word (256 same-address atomics cost ~10 us,
-// tools/lab/gridbar_lab.hip), two memory hops, the same numbers in the same order in every block -- and in the oracle
-// (oracle/kmcf_oracle_order.c: orc_pcg1_resident_order), which must agree bit for bit.
+// tools/lab/gridbar_lab.hip), two memory hops (one where the grid is at most 256 blocks: every block reads every block's
+// line itself), the same numbers in the same order in every block -- and in the tests' CPU restatement of this order,
+// which must agree bit for bit (kmcf_matrix_sum_plan exports resident_tpb / resident_g1 for it).
 // Measured before it was written: tools/lab/resident_lab.hip (881 tiles: 6.7 us per iteration with one block per CU).
 //
 // Every wait is bounded by the wall clock (KMCF_CGR_TIMEOUT_MS, default 4000): expiry sets an error word, every other

@@ -4,6 +4,7 @@
 // with 27-cell queries; the output is what those scans produce (columns ascending, diagonal included).
 // Everything lives in an anonymous namespace: each translation unit gets its own copy.
 #pragma once
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -147,6 +148,7 @@ struct host_cells {
     int *d_cell_start = nullptr;
     int *d_cell_items = nullptr;
     bool usable = true;   // false: fall back to brute force (tiny periodic grids)
+    unsigned long long bits_sum = 0;   // checksum of the coordinates as build_cells' synchronous host copy saw them (coords_seen_by_kernels)
     void release()
     {
         if (d_cell_start) hipFree(d_cell_start);
@@ -169,6 +171,15 @@ int build_cells(const double *d_x, const double *d_y, const double *d_z, int N, 
         lo[2] = std::min(lo[2], z[s]); hi[2] = std::max(hi[2], z[s]);
     }
     if (N == 0) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 0; }
+    {
+        unsigned long long acc = 0, w;
+        for (int s = 0; s < N; ++s) {
+            memcpy(&w, &x[s], 8); acc += w;
+            memcpy(&w, &y[s], 8); acc += 3 * w;
+            memcpy(&w, &z[s], 8); acc += 5 * w;
+        }
+        hc->bits_sum = acc;
+    }
     cell_grid &g = hc->g;
     g.wrap_y = g.wrap_z = 0;
     g.x0 = lo[0]; g.inv_x = 1.0 / edge; g.ncx = (int)std::floor((hi[0] - lo[0]) / edge) + 1;
@@ -201,6 +212,38 @@ int build_cells(const double *d_x, const double *d_y, const double *d_z, int N, 
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&hc->d_cell_items), items.size() * sizeof(int)));
     KMCF_HIP(hipMemcpy(hc->d_cell_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
     KMCF_HIP(hipMemcpy(hc->d_cell_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+    return KMCF_OK;
+}
+
+// The set-up kernels must see the coordinates the host copy above saw.  A kernel on stream `st` adds up the same
+// checksum (integer adds of the raw bits: order-free); a mismatch means the kernels would build their pattern from
+// arrays whose upload has not landed for them -- seen once as a silent wrong pattern (y and z still zero: DESIGN 11, "the
+// flake of the in-process groups"), now a loud KMCF_ERR_STATE.
+__global__ __launch_bounds__(KMCF_BLOCK) void coords_sum_kernel(int N, const double *__restrict__ x, const double *__restrict__ y,
+                                                                const double *__restrict__ z, unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < N; s += gridDim.x * blockDim.x)
+        acc += (unsigned long long)__double_as_longlong(x[s]) + 3ull * (unsigned long long)__double_as_longlong(y[s]) +
+               5ull * (unsigned long long)__double_as_longlong(z[s]);
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+int coords_seen_by_kernels(const host_cells &hc, const double *d_x, const double *d_y, const double *d_z, int N, hipStream_t st, const char *who)
+{
+    unsigned long long *d_sum = nullptr, h_sum = 0;
+    KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_sum), sizeof(unsigned long long)));
+    KMCF_HIP(hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), st));
+    coords_sum_kernel<<<grid1d(N, 1024), KMCF_BLOCK, 0, st>>>(N, d_x, d_y, d_z, d_sum);
+    KMCF_HIP(hipGetLastError());
+    KMCF_HIP(hipMemcpyAsync(&h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, st));
+    KMCF_HIP(hipStreamSynchronize(st));
+    hipFree(d_sum);
+    KMCF_CHECK(h_sum == hc.bits_sum, KMCF_ERR_STATE,
+               "%s: the set-up kernels do not see the site coordinates the host copy sees (checksum %llx against %llx): an upload of "
+               "the caller's arrays has not completed for this stream -- upload from pinned memory, or synchronise the upload's stream, "
+               "before the call (INTEGRATION.md, \"Arrays handed to the library\")", who, h_sum, hc.bits_sum);
     return KMCF_OK;
 }
 

@@ -373,7 +373,9 @@ extern "C" int kmcf_initialize_sparsity_K(kmcf_comm *c, const double *d_x, const
 
     host_cells hc;
     KMCF_TRY(build_cells(d_x, d_y, d_z, N, h_lattice, pbc, nn_dist, &hc));
-    int rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left, N_left + N_interface,
+    int rc = coords_seen_by_kernels(hc, d_x, d_y, d_z, N, kmcf_setup_stream(c), "kmcf_initialize_sparsity_K");
+    if (rc == KMCF_OK)
+        rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, N_left, N_left + N_interface,
                            &k->h_row_ptr, &k->h_col, kmcf_setup_stream(c));
     if (rc == KMCF_OK)
         rc = build_pattern(hc, d_x, d_y, d_z, h_lattice, pbc, nn_dist, N_left + disp, n_loc, 0, N_left,
@@ -705,6 +707,10 @@ extern "C" int kmcf_neighbor_list(kmcf_comm *c, const double *d_x, const double 
     host_cells hc;
     const double lattice[3] = {1, 1, 1};
     KMCF_TRY(build_cells(d_x, d_y, d_z, N, lattice, 0, nn_dist, &hc));
+    {
+        const int rcv = coords_seen_by_kernels(hc, d_x, d_y, d_z, N, kmcf_setup_stream(c), "kmcf_neighbor_list");
+        if (rcv != KMCF_OK) { hc.release(); return rcv; }
+    }
     int *d_over = nullptr;
     KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_over), sizeof(int)));
     hipStream_t ss = kmcf_setup_stream(c);                       // (the caller's stream: see kmcf_internal.hpp)

@@ -1210,6 +1210,22 @@ extern "C" int kmcf_initialize_sparsity_T(kmcf_comm *c, const double *d_site_x, 
     KMCF_HIP(hipMemcpy(ax.data(), t->d_ax, (size_t)Na * sizeof(double), hipMemcpyDeviceToHost));
     KMCF_HIP(hipMemcpy(ay.data(), t->d_ay, (size_t)Na * sizeof(double), hipMemcpyDeviceToHost));
     KMCF_HIP(hipMemcpy(az.data(), t->d_az, (size_t)Na * sizeof(double), hipMemcpyDeviceToHost));
+    {
+        // what the gather kernel read must be what a synchronous copy of the caller's arrays reads (the failure this
+        // guards against built a pattern from coordinates whose y and z were still zero: silently)
+        std::vector<double> sx((size_t)N);
+        const double *src[3] = {d_site_x, d_site_y, d_site_z};
+        const std::vector<double> *got[3] = {&ax, &ay, &az};
+        for (int q = 0; q < 3; ++q) {
+            KMCF_HIP(hipMemcpy(sx.data(), src[q], (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+            for (int a = 0; a < Na; ++a)
+                KMCF_CHECK(memcmp(&(*got[q])[(size_t)a], &sx[(size_t)t->h_atom_site[(size_t)a]], sizeof(double)) == 0, KMCF_ERR_STATE,
+                           "kmcf_initialize_sparsity_T: the gather kernel does not see the site coordinates the host copy sees (atom %d, "
+                           "coordinate %d: %.17g against %.17g): an upload of the caller's arrays has not completed for this stream -- "
+                           "upload from pinned memory, or synchronise the upload's stream, before the call", a, q, (*got[q])[(size_t)a],
+                           sx[(size_t)t->h_atom_site[(size_t)a]]);
+        }
+    }
 
     // atom-atom pattern of this rank's atom rows (calc_nnz_per_row_T / assemble_T_col_indices, "direct terms",
     // src/initialize_sparsity_T.cu:62-72, 166-177; the diagonal comes with it: dist 0 < nn_dist)

@@ -476,3 +476,18 @@ def test_dense_symmetric_tunnel_block_matches_bitmap_and_oracle(km, oracle, dev5
     assert c["st"]["iterations"] == b["st"]["iterations"] and c["im"] == b["im"]
     np.testing.assert_array_equal(c["m"], b["m"])
     np.testing.assert_array_equal(c["pw"], b["pw"])
+
+
+def test_in_process_builds_under_stress():
+    """tools/tmulti_stress.py as a regression test: the four variants of test_small_device_multirank cycle
+    after cycle in ONE process, device memory re-allocated and filled with junk in between -- the history in which an
+    in-process group once built a T pattern from coordinates its kernels did not see yet.  The set-up
+    kernels run on the caller's stream since then, and every set-up now compares what its kernels see with a
+    synchronous host copy (KMCF_ERR_STATE on a mismatch: loud instead of a silently wrong pattern)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tmulti_stress.py"), "10", "poison"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert "0 failures in 10 cycles" in out.stdout, out.stdout[-2000:]

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(KMCF_BLOCK) void select_event_kernel(
 // per lane, then the butterfly.
 constexpr int EV_RT = 32;
 constexpr int EV_PB = 1024;                                 // threads of the persistent block
-constexpr int EV_GLDS = 1024;                               // group sums the block keeps in LDS (8.4 M rows; beyond: read from gsum)
+constexpr int EV_GLDS = 512;                                // group sums the block keeps in LDS (4.2 M rows; beyond: read from gsum)
+constexpr int EV_ST = 4;                                    // tiles per "supertile": one lane's share of a group sum (ev_group_sum)
+constexpr int EV_STMAX = 12800;                             // supertile sums the block keeps in (dynamic) LDS: 100 KB = 1.64 M rows
 constexpr int EV_BMAX = 512;                                // events per batch
 constexpr int EV_AFF = 2 * 63 + 2;                          // rows an event touches at most (nn <= 63: the entries of two wavefronts)
 constexpr int EV_TREL = 2048;                               // range of the tile claim table (tiles above the smallest touched one)
@@ -540,6 +542,18 @@ __device__ __forceinline__ double ev_group_sum(const double *__restrict__ tsum, 
     return ev_wave_sum(s);
 }
 
+// ... the same, leaving every lane's share (the sum of its supertile) in st[g * 64 + lane] when st != nullptr
+__device__ __forceinline__ double ev_group_sum_st(const double *__restrict__ tsum, long long g, long long n_tiles, double *st)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t0 = g * EV_GROUP + 4 * lane;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += t0 + k < n_tiles ? tsum[t0 + k] : 0.0;
+    if (st && t0 < n_tiles) st[g * (EV_GROUP / EV_ST) + lane] = s;
+    return ev_wave_sum(s);
+}
+
 // level 0: row sums (a wavefront per row), 1: tile sums (half a wavefront per tile), 2: group sums (a wavefront per group)
 __global__ __launch_bounds__(KMCF_BLOCK) void ev_tree_level_kernel(int level, long long n_out, long long n_in, int nn,
                                                                    const double *__restrict__ in, double *__restrict__ out)
@@ -569,6 +583,7 @@ struct event_batch_args {
     int count, nn, nbatch, trel_max, number;
     long long n_tiles, n_groups;
     double inv_freq;
+    int n_st;      // > 0: the sums of all n_st supertiles (EV_ST tiles = 128 rows each) are kept in LDS for the batch
 };
 
 __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
@@ -600,6 +615,13 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
     __shared__ double s_tnew[EV_AFF];                      // per owning entry: new sum of its tile
     __shared__ int s_own[EV_OWN], s_ocnt[2];               // the owning entries, listed (two lists: see the claims), and how many
     __shared__ double s_g[EV_GLDS], s_u[EV_BMAX], s_nlog[EV_BMAX];
+    // Round 4: one level of the selection walk out of LDS instead of memory.  A group sum is formed as four consecutive
+    // tile sums per lane, then the butterfly (ev_group_sum): a lane's share -- the sum of a "supertile" of 4 tiles = 128
+    // rows -- is kept here for ALL supertiles (100 KB at 40 nm), refreshed for free wherever a group sum is re-formed.
+    // The walk is then groups (LDS) -> supertiles of the group (LDS) -> the 128 row sums of the supertile (memory) -> the
+    // row's slots (memory): two dependent round trips instead of three (the group's 256 tile sums came from memory).
+    extern __shared__ double s_st[];
+    const bool st_lds = A.n_st > 0;
     const int nn = A.nn, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int NW = EV_PB / 64;
     const int n_aff = 2 * nn + 2;
@@ -616,6 +638,14 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
     // batch's uniforms and -log(u) of the residence times.  Each is one global round trip less in front of an event.
     const bool g_lds = A.n_groups <= EV_GLDS;
     if (g_lds) for (int g = t; g < (int)A.n_groups; g += EV_PB) s_g[g] = gsum[g];
+    if (st_lds)
+        for (int q = t; q < A.n_st; q += EV_PB) {              // (the order of ev_group_sum's per-lane part)
+            const long long t0 = (long long)EV_ST * q;
+            double sm = 0.0;
+#pragma unroll
+            for (int k = 0; k < EV_ST; ++k) sm += t0 + k < A.n_tiles ? tsum[t0 + k] : 0.0;
+            s_st[q] = sm;
+        }
     const double *gs = g_lds ? s_g : gsum;
     if (t < A.nbatch) { s_u[t] = batch_u[2 * t]; s_nlog[t] = -log(batch_u[2 * t + 1]); }    // (:479; A.nbatch <= EV_BMAX)
     const int trel_max = A.trel_max;                       // EV_TREL (tests: smaller, to reach the out-of-range path)
@@ -631,12 +661,21 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
             double acc = 0.0;
             int g = wave_search<4>(gs, (int)A.n_groups, number, &acc);
             if (g < 0) g = 0;
-            const long long b0 = (long long)g * EV_GROUP;
-            int b = wave_search<4>(tsum + b0, (int)(b0 + EV_GROUP < A.n_tiles ? EV_GROUP : A.n_tiles - b0), number, &acc);
-            const long long tile = b0 + (b < 0 ? 0 : b);
-            const long long r0 = tile * EV_RT;
-            int r = wave_search<1>(rsum + r0, (int)(r0 + EV_RT < A.count ? EV_RT : A.count - r0), number, &acc);
-            const long long row = r0 + (r < 0 ? 0 : r);
+            long long row;
+            if (st_lds) {
+                const int q0 = g * (EV_GROUP / EV_ST);
+                int q = wave_search<1>(s_st + q0, min(EV_GROUP / EV_ST, A.n_st - q0), number, &acc);
+                const long long r0 = (long long)(q0 + (q < 0 ? 0 : q)) * (EV_ST * EV_RT);
+                int r = wave_search<2>(rsum + r0, (int)(r0 + EV_ST * EV_RT < A.count ? EV_ST * EV_RT : A.count - r0), number, &acc);
+                row = r0 + (r < 0 ? 0 : r);
+            } else {
+                const long long b0 = (long long)g * EV_GROUP;
+                int b = wave_search<4>(tsum + b0, (int)(b0 + EV_GROUP < A.n_tiles ? EV_GROUP : A.n_tiles - b0), number, &acc);
+                const long long tile = b0 + (b < 0 ? 0 : b);
+                const long long r0 = tile * EV_RT;
+                int r = wave_search<1>(rsum + r0, (int)(r0 + EV_RT < A.count ? EV_RT : A.count - r0), number, &acc);
+                row = r0 + (r < 0 ? 0 : r);
+            }
             // the row's slots together with their neighbour ids and event types: the chosen slot's j and type arrive with
             // the probabilities instead of one round trip after them -- and the ids ARE row i's share of s_rows
             const long long sl = row * nn + (lane < nn ? lane : 0);
@@ -890,7 +929,7 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
         if (fastp) {
             for (int k = wv + NW; k < ngrp; k += NW) {         // (more than 16 touched groups: the tile sums are in memory by now)
                 const long long g = group_of(k);
-                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                const double v = ev_group_sum_st(tsum, g, A.n_tiles, st_lds ? s_st : nullptr);
                 if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
             }
             if (wv < ngrp) {
@@ -902,20 +941,21 @@ __global__ __launch_bounds__(EV_PB) void event_batch_kernel(
                     if (trel >= 0 && trel < trel_max) { const int e = s_tent[trel]; if (e >= 0) gp[k] = s_tnew[e]; }
                     s += gp[k];
                 }
+                if (st_lds && g * EV_GROUP + 4 * lane < A.n_tiles) s_st[g * (EV_GROUP / EV_ST) + lane] = s;
                 const double v = ev_wave_sum(s);
                 if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
             }
         } else {
             for (int k = wv; k < ngrp; k += NW) {              // the groups in the mask's range ...
                 const long long g = group_of(k);
-                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                const double v = ev_group_sum_st(tsum, g, A.n_tiles, st_lds ? s_st : nullptr);
                 if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
             }
             for (int e = wv; e < n_aff; e += NW) {             // ... and, entry by entry, those beyond it
                 const int row = s_rows[e];
                 if (row < 0 || !(s_uniq[e] & 2)) continue;        // wavefront-uniform
                 const long long g = (row / EV_RT) / EV_GROUP;
-                const double v = ev_group_sum(tsum, g, A.n_tiles);
+                const double v = ev_group_sum_st(tsum, g, A.n_tiles, st_lds ? s_st : nullptr);
                 if (lane == 0) { gsum[g] = v; if (g_lds) s_g[g] = v; }
             }
         }
@@ -1147,12 +1187,29 @@ extern "C" int kmcf_execute_kmc_step(kmcf_comm *c, int N, const int *h_count, co
                 event_batch_args A;
                 A.count = count; A.nn = nn; A.nbatch = nbatch; A.trel_max = trel_max; A.n_tiles = n_tiles2; A.n_groups = n_groups2; A.inv_freq = 1 / freq;
                 A.number = pin_ok ? ++w->batch_number : 0;
+                // the supertile sums in LDS where they fit beside the kernel's own arrays (KMCF_EVENTS_ST=0: the round-3 walk)
+                A.n_st = 0;
+                size_t dyn = 0;
+                {
+                    static const bool st_on = !(getenv("KMCF_EVENTS_ST") && atoi(getenv("KMCF_EVENTS_ST")) == 0);
+                    const long long n_st = (n_tiles2 + EV_ST - 1) / EV_ST;
+                    hipFuncAttributes fa;
+                    if (st_on && n_groups2 <= EV_GLDS && n_st <= EV_STMAX &&
+                        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(event_batch_kernel)) == hipSuccess &&
+                        fa.sharedSizeBytes + (size_t)n_st * sizeof(double) <= (size_t)160 * 1024 &&
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(event_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(n_st * sizeof(double))) == hipSuccess) {
+                        A.n_st = (int)n_st;
+                        dyn = (size_t)n_st * sizeof(double);
+                    }
+                    (void)hipGetLastError();
+                }
                 if (pin_ok)
-                    event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
-                                                                d_site_charge, h_log, h_tot, h_u, const_cast<event_batch_state *>(p_state));
+                    event_batch_kernel<<<1, EV_PB, dyn, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
+                                                                  d_site_charge, h_log, h_tot, h_u, const_cast<event_batch_state *>(p_state));
                 else
-                    event_batch_kernel<<<1, EV_PB, 0, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
-                                                                d_site_charge, d_evlog, d_totlog, d_u, d_state);
+                    event_batch_kernel<<<1, EV_PB, dyn, st>>>(A, d_prob, d_type, d_neigh_idx, w->d_rsum, w->d_tsum2, w->d_gsum2, d_site_element,
+                                                                  d_site_charge, d_evlog, d_totlog, d_u, d_state);
             }
             for (int ev = 0; ev < nbatch && !persistent; ++ev) {
                 select_event_kernel<true><<<1, KMCF_BLOCK, 0, st>>>(M, nb, ng, start_i, nn, -1.0, 0.0, d_gsum, d_tsum, d_prob, d_type,

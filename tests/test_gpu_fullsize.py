@@ -314,7 +314,7 @@ def test_full_size_current_and_heat(full, km):
         print("T 40 nm, reference window: %d tunnel points, %d entries (%.0f %% dense; stored as %s, %.2f GB per application), first assembly %.3f s (with allocation), "
               "%d iterations, assembly %.1f ms, solve %.1f ms (%.2f ms per iteration), device memory %.1f GB more than before"
               % (iw["tunnel_points"], iw["nnz_tunnel"], 100.0 * iw["nnz_tunnel"] / iw["tunnel_points"] ** 2,
-                 "dense symmetric tiles" if iw["tunnel_dense"] else "bitmap + packed values", iw["tunnel_bytes"] * 1e-9, t_asm,
+                 ("bitmap + packed values", "dense symmetric tiles", "jagged symmetric tiles")[iw["tunnel_dense"]], iw["tunnel_bytes"] * 1e-9, t_asm,
                  st_w["iterations"], st_w["ms_assembly"], st_w["ms_solve"], st_w["ms_solve"] / max(st_w["iterations"], 1), (free0 - free1) / 1e9))
         assert st_w["iterations"] == 100 and np.isfinite(im_w)
         pw_w = buf.site_power.cpu().numpy()

@@ -5,6 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+PART=${1:-all}          # a | b | all   (two gpurun calls keep each under the call's time limit)
+if [ "$PART" != "b" ]; then
 echo "== bench: kernel trace + stats (the driver's command line)"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o b --output-format csv -- \
     python3 $R/bench.py --steps 20 --warmup 5 --no-hbm-probe > $OUT/bench_line.json 2> $OUT/stats.log   # (the probe launches the SAME kernel on a larger matrix: profiled separately below, so that this summary's average is the 40 nm launch)
@@ -21,6 +23,8 @@ python3 $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc
 python3 $R/tools/pmc_summary.py $OUT/pmcbig_FETCH_SIZE $OUT/pmcbig_WRITE_SIZE $OUT/pmc_spmv_hbm 3596760 "synthetic_40nm_crossbar(tiles=12,fill=0.52,lines=2,seed=40,bwmin)"
 echo "== big device: kernel stats"
 LAB_TILES=12 rocprofv3 --kernel-trace --stats -d $OUT/statsbig -o b --output-format csv -- python3 $R/tools/spmv_lab.py "SELL=1" > $OUT/statsbig.txt 2>&1
+fi
+if [ "$PART" = "a" ]; then echo done-a; exit 0; fi
 echo "== extras"
 E=$OUT/extras; mkdir -p $E
 python3 $R/bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $E/bench_steps20.json

@@ -109,7 +109,12 @@ def test_full_size_solve_properties(full):
     # the stopping rule holds for the true residual too (z = r / diag): sqrt(r.z / b.b)
     r = vec["rhs"] - _spmv(full, v)
     true_rel = np.sqrt(np.dot(r, r * vec["dinv"]) / np.dot(vec["rhs"], vec["rhs"]))
-    assert true_rel <= 50 * tol, (true_rel, tol)         # recurrence vs true residual after a few hundred iterations
+    # What the factor bounds: the gap between the recurrence's residual (which the stopping rule tests) and the TRUE
+    # residual b - K x in the same norm, after ~150 updates r -= alpha K p of a system whose entries span 1 ... 1e-8.
+    # Each update leaves O(eps |alpha| |K| |p|) unaccounted for; summed they amount to 1.2e-9 / 3.6e-10 = 3.3 x the
+    # tolerance on the 5 nm system after 320 iterations (conftest.py: TRUE_RESIDUAL_BAR, the oracle's own figure); 50 x is a
+    # regression bar an order above that -- a wrong SpMV entry or a dropped update misses it by factors of 1e6.
+    assert true_rel <= 50 * tol, (true_rel, tol)
     # discrete maximum principle: between the contact potentials -Vd/2 and +Vd/2
     assert v.min() >= -d["Vd"] / 2 - 1e-5 and v.max() <= d["Vd"] / 2 + 1e-5
     assert v.min() < -0.4 * d["Vd"] and v.max() > 0.4 * d["Vd"]                    # and it does span them

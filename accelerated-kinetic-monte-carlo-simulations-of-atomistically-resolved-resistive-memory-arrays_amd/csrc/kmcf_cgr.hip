@@ -169,6 +169,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     extern __shared__ double cgr_lds[];
     double *red = cgr_lds + (size_t)TPB * ND * CGR_W;      // [CGR_NV][16] wavefront sums
     double *bc = red + CGR_NV * 16;                        // [CGR_NV] reduced sums, for every thread; flat reduction: [CGR_NV][4] wave sums
+    double *zblk = bc + 16;                                // [TPB * 256] the block's own rows of the vector being multiplied
     const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), gw = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *xs = cgr_lds + (size_t)sub * ND * CGR_W;
@@ -181,6 +182,19 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     int wc[CGR_WQ];
 #pragma unroll
     for (int q = 0; q < CGR_WQ; ++q) wc[q] = (q * KMCF_BLOCK + t < d.w) ? A.wcol[d.z + q * KMCF_BLOCK + t] : -1;
+    // Window columns that are rows of a sibling tile of this block (consecutive tiles are neighbours in space: a third
+    // of a tile's outside columns, tools/lab/window_stats.py) come out of LDS, where every lane leaves its own value
+    // (zblk, indexed by row - the block's first row), not through the granules: fewer requests around the L2s.
+    int rb0 = 0, rb1 = 0;                          // the block's rows [rb0, rb1)
+    if (TPB > 1) {
+        const int cf = blockIdx.x * TPB, cl = min(cf + TPB, A.n_tiles) - 1;
+        const int4 df = A.tile4[cf], dl = A.tile4[cl];
+        rb0 = __builtin_amdgcn_readfirstlane(df.x);
+        rb1 = __builtin_amdgcn_readfirstlane(dl.x + dl.y);
+    }
+    bool sib[CGR_WQ];
+#pragma unroll
+    for (int q = 0; q < CGR_WQ; ++q) sib[q] = TPB > 1 && wc[q] >= rb0 && wc[q] < rb1;
     sell_pair pk[NQ];
     {
         const sell_pair *sp = A.stream + sw.x + lane;
@@ -230,7 +244,8 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         double g[CGR_WQ];
         bool need[CGR_WQ];
 #pragma unroll
-        for (int q = 0; q < CGR_WQ; ++q) { g[q] = 0.0; need[q] = wc[q] >= 0; }
+        for (int q = 0; q < CGR_WQ; ++q) { g[q] = 0.0; need[q] = wc[q] >= 0 && !sib[q]; }
+        if (TPB > 1 && has_row) zblk[row - rb0] = own;
         while (true) {
             bool all = true;
 #pragma unroll
@@ -259,6 +274,12 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             asm volatile("" ::: "memory");                 // (the next pass loads again)
         }
         CGR_T(tp_gather);
+        if (TPB > 1) {
+            __syncthreads();                               // (every lane's own value is in zblk)
+#pragma unroll
+            for (int q = 0; q < CGR_WQ; ++q)
+                if (sib[q]) g[q] = zblk[wc[q] - rb0];
+        }
 #pragma unroll
         for (int k = 0; k < ND; ++k) xs[k * CGR_W + t] = dv[k] * own;                 // (lanes without a row: own = 0)
 #pragma unroll
@@ -495,7 +516,7 @@ struct cgr_launch_info { int per_cu; size_t lds; };
 template <int NQ, int ND, int TPB>
 int cgr_run(const cgr_args &A, bool launch, hipStream_t st, cgr_launch_info *info)
 {
-    const size_t lds = ((size_t)TPB * ND * CGR_W + CGR_NV * 16 + 16) * sizeof(double);
+    const size_t lds = ((size_t)TPB * ND * CGR_W + CGR_NV * 16 + 16 + (TPB > 1 ? TPB * KMCF_BLOCK : 0)) * sizeof(double);
     auto kern = cgr_kernel<NQ, ND, TPB>;
     KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (info) {

@@ -77,6 +77,7 @@ struct cgr_args {
     long long timeout;
     int limit, check_tol;
     double tol2;
+    int sibling_lds;                 // 1: window columns owned by a sibling tile of the block come out of LDS (KMCF_CGR_SIB=0: through the granules)
     // groups of ranks (peer-to-peer transport; kmcf_p2p_dev.hpp): nranks == 1 -> everything below unused
     int nranks, rank, n_loc;
     const int *put_row, *putr_ptr;             // per internal row: its entry list (-1: not sent) | entries of a sent row
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     }
     bool sib[CGR_WQ];
 #pragma unroll
-    for (int q = 0; q < CGR_WQ; ++q) sib[q] = TPB > 1 && wc[q] >= rb0 && wc[q] < rb1;
+    for (int q = 0; q < CGR_WQ; ++q) sib[q] = TPB > 1 && A.sibling_lds && wc[q] >= rb0 && wc[q] < rb1;
     sell_pair pk[NQ];
     {
         const sell_pair *sp = A.stream + sw.x + lane;
@@ -733,6 +734,7 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     A.timeout = (long long)rate_khz * timeout_ms;
     if (c->nranks > 1 && c->p2p && !getenv("KMCF_CGR_TIMEOUT_MS")) A.timeout = c->p2p->timeout_ticks;      // (a group: the transport's bound, KMCF_P2P_TIMEOUT_MS)
     A.limit = limit; A.check_tol = fixed_iters > 0 ? 0 : 1; A.tol2 = tol * tol;
+    A.sibling_lds = !(getenv("KMCF_CGR_SIB") && atoi(getenv("KMCF_CGR_SIB")) == 0);
     A.nranks = c->nranks; A.rank = c->rank; A.n_loc = m->n_loc;
     if (c->nranks > 1) {
         const kmcf_p2p_halo *h = m->p2p;

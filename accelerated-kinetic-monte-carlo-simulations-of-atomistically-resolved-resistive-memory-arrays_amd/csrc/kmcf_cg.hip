@@ -327,7 +327,7 @@ int cg_chunk_check(kmcf_comm *c, const kmcf_scalars *S, hipStream_t st, bool *do
 }
 
 // Reads back the scalars of the solve enqueued last (after ONE stream synchronisation) and fills `stats`.
-int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *stats)
+int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *stats, bool loop_time = true)
 {
     kmcf_comm *c = m->comm;
     KMCF_HIP(hipStreamSynchronize(c->stream));
@@ -341,9 +341,11 @@ int pcg_collect(kmcf_matrix *m, double tol2, int absolute, kmcf_solve_stats_t *s
         stats->rz = hS.rz_last;
         stats->relres = std::sqrt(hS.rz_last / hS.bb);
         stats->converged = (hS.done != 0) || !((absolute ? hS.rz_last : hS.rz_last / hS.bb) > tol2);
-        float ms = 0.f;
-        KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-        stats->ms_solve = ms;
+        if (loop_time) {                                   // (kmcf_pcg_jacobi times the whole call instead: the first
+            float ms = 0.f;                                //  hipEventElapsedTime after a synchronisation costs ~13 us)
+            KMCF_HIP(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+            stats->ms_solve = ms;
+        }
     }
     return KMCF_OK;
 }
@@ -809,12 +811,13 @@ static int pcg_workspace_flags(kmcf_matrix *m, bool precond, double tol, int max
 
 // The single-reduction recurrence as ONE register-resident launch (kmcf_cgr.hip), for matrices whose tiles are all
 // resident at once.  Workspace in, workspace out, scalars in d_S -- like the loops.
-static int pcg_resident(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
+static int pcg_resident(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags, bool classic)
 {
     kmcf_comm *c = m->comm;
     hipStream_t st = c->stream;
     KMCF_HIP(hipEventRecord(c->ev_t0, st));
-    KMCF_TRY(kmcf_cgr_solve(m, precond, tol, max_it, fixed_iters));
+    KMCF_TRY(kmcf_cgr_solve(m, precond, tol, max_it, fixed_iters, classic));
+    m->last_solve_resident = true;
     KMCF_HIP(hipEventRecord(c->ev_t1, st));
     if (flags & 2) return KMCF_OK;                 // the caller's output kernel writes the scalars to the host
     KMCF_HIP(hipMemcpyAsync(c->h_scal, m->d_S, sizeof(kmcf_scalars), hipMemcpyDeviceToHost, st));
@@ -823,13 +826,20 @@ static int pcg_resident(kmcf_matrix *m, bool precond, double tol, int max_it, in
 
 static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
 {
+    m->last_solve_resident = false;
     // classic = the reference's recurrence and operation order (default for one rank);
     // cg1r = single-reduction variant (default for multi-rank groups)
     if (kmcf_cg_single_reduction(m)) {
-        if (kmcf_cgr_usable(m) && (fixed_iters > 0 || max_it > 0)) return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags);
+        if (kmcf_cgr_usable(m) && (fixed_iters > 0 || max_it > 0)) return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags, false);
         if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
         return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }
+    // the reference's recurrence as ONE register-resident launch, one rank, for SMALL matrices: with two reduction points
+    // per iteration it pays two waits for everybody's sums, which beats three kernel boundaries only while the blocks are
+    // few (us per iteration, resident / loop: 5 nm device, 286 tiles: 9.7 / 10.9; a rank's eighth of the 40 nm matrix, 881
+    // tiles: 16.3 / 14.8) -- up to 512 tiles (KMCF_CGR_CLASSIC_TILES)
+    if (kmcf_cgr_classic_applies(m) && (fixed_iters > 0 || max_it > 0) && kmcf_cgr_usable(m))
+        return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags, true);
     if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats, flags);
     return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats, flags);
 }
@@ -1024,13 +1034,13 @@ extern "C" int kmcf_pcg_jacobi(kmcf_matrix *m, double *d_r, double *d_x, const d
     }
     KMCF_TRY(pcg_workspace_flags(m, d_diag_inv != nullptr, relative_tolerance, max_iterations, fixed_iters, stats, 1 | 2));
     const double t_b = trace ? now() : 0.0;
-    const bool tail_here = !(c->nranks > 1 || c->force_collectives) && !kmcf_cg_single_reduction(m) && n > 0;
+    const bool tail_here = !(c->nranks > 1 || c->force_collectives) && !kmcf_cg_single_reduction(m) && n > 0 && !m->last_solve_resident;
     cg_out_kernel<<<perm_grid(std::max(n, 1)), KMCF_BLOCK, 0, c->stream>>>(n, m->d_perm, m->d_r, m->d_x, m->d_p, d_r, d_x, m->d_S, c->h_scal,
                                                                            tail_here ? pr1(m->d_part_b, vec_grid(n)) : pr_none());
     KMCF_HIP(hipGetLastError());
     KMCF_HIP(hipEventRecord(c->ev_call1, c->stream));
     // results visible on return (:271 hipDeviceSynchronize)
-    const int rc = pcg_collect(m, relative_tolerance * relative_tolerance, 0, stats);
+    const int rc = pcg_collect(m, relative_tolerance * relative_tolerance, 0, stats, false);
     if (rc == KMCF_OK && stats) {
         // device time of everything this call enqueued: vectors in, r = b - A x0, the iterations, vectors out
         float ms = 0.f;

@@ -77,6 +77,7 @@ struct cgr_args {
     long long timeout;
     int limit, check_tol;
     double tol2;
+    int classic;                     // 1: the reference's recurrence (two reduction points per iteration); 0: the single-reduction form
     int sibling_lds;                 // 1: window columns owned by a sibling tile of the block come out of LDS (KMCF_CGR_SIB=0: through the granules)
     // groups of ranks (peer-to-peer transport; kmcf_p2p_dev.hpp): nranks == 1 -> everything below unused
     int nranks, rank, n_loc;
@@ -210,6 +211,10 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     const double b_i = has_row ? A.r[row] : 0.0;
     double x = has_row ? A.x[row] : 0.0;
     unsigned int seq = *A.seq;                   // (read by every block before block 0 overwrites it at the very end)
+    // Every publication and every reduction takes the next sequence number (unique over the life of the buffers); which
+    // of its two buffers a publication / a reduction uses alternates on its own count (zpar / rpar), the same in every
+    // block and on every rank: both recurrences below publish and reduce in a fixed pattern.
+    int zpar = 1, rpar = 1;
     cgr_wait W{wall_clock64(), A.timeout, A.d_err, A.h_err, 0, false};
 #ifdef KMCF_CGR_PROFILE
     long long tp_gather = 0, tp_row = 0, tp_red1 = 0, tp_red2 = 0, tp_red3 = 0, tp_mark = 0;
@@ -232,15 +237,17 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         if (pr >= 0) { put0 = A.putr_ptr[pr]; put1 = A.putr_ptr[pr + 1]; }
     }
     auto publish = [&](double v) {
+        ++seq;
+        zpar ^= 1;
         if (has_row) {
-            if (seq & 1) ll_store16(zrs[1], 16u * (unsigned int)row, v, seq);
+            if (zpar) ll_store16(zrs[1], 16u * (unsigned int)row, v, seq);
             else ll_store16(zrs[0], 16u * (unsigned int)row, v, seq);
-            for (int e = put0; e < put1; ++e) ll_store_sys(A.putr_ll[e] + (seq & 1) * A.putr_ll_stride[e], v, seq);
+            for (int e = put0; e < put1; ++e) ll_store_sys(A.putr_ll[e] + zpar * A.putr_ll_stride[e], v, seq);
         }
     };
     // y_row = sum of the row's products with version `seq` of the vector whose own entry is `own`
     auto spmv = [&](double own) -> double {
-        const __amdgpu_buffer_rsrc_t zb = (seq & 1) ? zrs[1] : zrs[0];
+        const __amdgpu_buffer_rsrc_t zb = zpar ? zrs[1] : zrs[0];
         CGR_T0();
         double g[CGR_WQ];
         bool need[CGR_WQ];
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             for (int q = 0; q < CGR_WQ; ++q)
                 if (need[q]) {
                     bool got;
-                    if (multi && wc[q] >= A.n_loc) got = ll_try_sys(A.halo_ll + (seq & 1) * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc), seq, g[q]);
+                    if (multi && wc[q] >= A.n_loc) got = ll_try_sys(A.halo_ll + zpar * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc), seq, g[q]);
                     else got = ll_try16(zb, 16u * (unsigned int)wc[q], seq, g[q]);
                     if (got) need[q] = false;
                     else all = false;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                 for (int q = 0; q < CGR_WQ; ++q)
                     if (need[q] && (tid & 63) == __ffsll((long long)__ballot(need[q])) - 1) {
                         const bool hal = multi && wc[q] >= A.n_loc;
-                        const u64 *pp = hal ? A.halo_ll + (seq & 1) * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc) : A.zll + (size_t)(seq & 1) * A.zwords + 2 * (size_t)wc[q];
+                        const u64 *pp = hal ? A.halo_ll + zpar * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc) : A.zll + (size_t)zpar * A.zwords + 2 * (size_t)wc[q];
                         printf("cgr gather timeout: rank %d block %d tid %d seq %u col %d (%s, n_loc %d) words %llx %llx\n", A.rank, (int)blockIdx.x, tid, seq, wc[q],
                                hal ? "halo" : "own", A.n_loc, (unsigned long long)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
                                (unsigned long long)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         if (nv > 2) v2 = kmcf_wave_sum64(v2);
         if (lane == 0) { red[gw] = v0; red[16 + gw] = v1; red[32 + gw] = v2; }
         __syncthreads();
-        u64 *sl = A.slot + ((size_t)(rs & 1) * A.nblocks + blockIdx.x) * CGR_LINE;
+        u64 *sl = A.slot + ((size_t)rpar * A.nblocks + blockIdx.x) * CGR_LINE;
         if (tid < nv) {                                    // tile sums (w0 + w1) + (w2 + w3), tiles in pairs
             const double *w = red + 16 * tid;
             double tsum[TPB];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             double bsum = tsum[0];
             if (TPB == 2) bsum = tsum[0] + tsum[1];
             if (TPB == 4) bsum = (tsum[0] + tsum[1]) + (tsum[2] + tsum[3]);
-            if (A.g1 == 0) ll_store16((rs & 1) ? srs[1] : srs[0], 128u * blockIdx.x + 16u * tid, bsum, rs);
+            if (A.g1 == 0) ll_store16(rpar ? srs[1] : srs[0], 128u * blockIdx.x + 16u * tid, bsum, rs);
             else ll_store(sl + 2 * tid, bsum, rs);
         }
         CGR_T(tp_red1);
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             if (gw < 4) {
                 const int q = 64 * gw + lane;
                 const bool mine = q < A.nblocks;
-                const __amdgpu_buffer_rsrc_t sb = (rs & 1) ? srs[1] : srs[0];
+                const __amdgpu_buffer_rsrc_t sb = rpar ? srs[1] : srs[0];
                 double g[CGR_NV] = {0.0, 0.0, 0.0};
                 bool need[CGR_NV] = {mine, mine, mine && nv > 2};
                 while (true) {
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         if (gw == 0 && blockIdx.x % A.g1 == 0) {           // leader of a group: one lane per block of the group
             const int q = blockIdx.x + lane;
             const bool mine = lane < A.g1 && q < A.nblocks;
-            const u64 *sq = A.slot + ((size_t)(rs & 1) * A.nblocks + (mine ? q : blockIdx.x)) * CGR_LINE;
+            const u64 *sq = A.slot + ((size_t)rpar * A.nblocks + (mine ? q : blockIdx.x)) * CGR_LINE;
             double g[CGR_NV] = {0.0, 0.0, 0.0};
             bool need[CGR_NV] = {mine, mine, mine && nv > 2};
             while (true) {
@@ -377,13 +384,13 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             }
             g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
             if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);
-            u64 *gs = A.gslot + ((size_t)(rs & 1) * A.ngroups + blockIdx.x / A.g1) * CGR_LINE;
+            u64 *gs = A.gslot + ((size_t)rpar * A.ngroups + blockIdx.x / A.g1) * CGR_LINE;
             if (lane < nv) ll_store(gs + 2 * lane, lane == 0 ? g[0] : (lane == 1 ? g[1] : g[2]), rs);
             CGR_T(tp_red2);
         }
         if (gw == 1) {                                     // every block: one lane per group
             const bool mine = lane < A.ngroups;
-            const u64 *gq = A.gslot + ((size_t)(rs & 1) * A.ngroups + (mine ? lane : 0)) * CGR_LINE;
+            const u64 *gq = A.gslot + ((size_t)rpar * A.ngroups + (mine ? lane : 0)) * CGR_LINE;
             double g[CGR_NV] = {0.0, 0.0, 0.0};
             bool need[CGR_NV] = {mine, mine, mine && nv > 2};
             while (true) {
@@ -410,10 +417,13 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     // ... and over the ranks of a group: this rank's sums (the same in every block) go to a line per rank in every peer's
     // reduction zone; every block adds the P lines of its own zone, one lane per rank (butterfly): the same numbers in the
     // same order on every rank
-    auto reduce = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV], unsigned int rs) -> bool {
+    auto reduce = [&](int nv, double v0, double v1, double v2, double (&out)[CGR_NV]) -> bool {
+        ++seq;
+        rpar ^= 1;
+        const unsigned int rs = seq;
         const bool ok = reduce_rank(nv, v0, v1, v2, out, rs);
         if (!multi) return ok;
-        const size_t par = rs & 1;
+        const size_t par = (size_t)rpar;
         if (blockIdx.x == 0 && gw == 0 && lane < A.nranks) {
             u64 *dst = A.red_peer[lane] + (par * P2P_MAXR + A.rank) * P2P_FS;
             ll_store_sys(dst, out[0], rs);
@@ -445,54 +455,84 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         return ok && bad == 0;
     };
 
-    // ---- r = b - A x0 ; z = r .* dinv ; gamma = (r, z) ; b.b                 (dist_conjugate_gradient.cpp:178-213)
-    ++seq;
+    // ---- r = b - A x0 ; z = r .* dinv ; (r, z) ; b.b                          (dist_conjugate_gradient.cpp:178-213)
     publish(x);
     const double ax = spmv(has_row ? x : 0.0);
     double r = b_i + (-1.0) * ax;
     double z = r * di;
     double gp = r * z, bbp = b_i * b_i;
     double p = 0.0, s = 0.0;
-    ++seq;
-    publish(z);
-    // ---- loop (:217-266 in the single-reduction form, kmcf_cg.hip: cg1_update_kernel)
     double bb = 0.0, g_old = 0.0, a_old = 0.0, rz_last = 0.0, pAp = 0.0;
     int iters = 0, done = 0;
     bool ok = true;
-    for (int k = 1; k <= A.limit; ++k) {
-        const bool first = k == 1;
-        const double w = spmv(has_row ? z : 0.0);
+    if (A.classic) {
+        // ---- the reference's recurrence and operation order (:217-266; kmcf_cg.hip: cg_p_kernel, cg_xr_kernel): two
+        // reduction points per iteration -- p.Ap, then r.z
         double sums[CGR_NV];
-        ok = reduce(first ? 3 : 2, gp, z * w, bbp, sums, seq);
-        if (!ok) break;
-        const double gamma = sums[0], delta = sums[1];
-        if (first) bb = sums[2];
-        const bool go = A.check_tol ? (gamma / bb > A.tol2) : true;
-        rz_last = gamma;
-        if (!go) { done = 1; break; }
-        double beta = 0.0, alpha;
-        if (first) alpha = gamma / delta;
-        else {
-            beta = gamma / g_old;
-            alpha = gamma / (delta - beta * gamma / a_old);
+        ok = reduce(2, gp, bbp, 0.0, sums);
+        double rz = sums[0], rz_prev = 0.0;
+        bb = sums[1];
+        for (int k = 1; k <= A.limit && ok; ++k) {
+            const bool first = k == 1;
+            const bool go = A.check_tol ? (rz / bb > A.tol2) : true;                       // :217
+            rz_last = rz;
+            if (!go) { done = 1; break; }
+            ++iters;
+            if (first) p = z;                                                                  // :226 dcopy(z -> p)
+            else { const double beta = rz / rz_prev; p = beta * p + z; }                      // :220-222 dscal, daxpy
+            publish(p);
+            const double Ap = spmv(has_row ? p : 0.0);
+            ok = reduce(2, p * Ap, 0.0, 0.0, sums);
+            if (!ok) break;
+            pAp = sums[0];
+            const double a = rz / pAp, na = -a;                                               // :240
+            x = x + a * p;                                                                     // :243
+            r = r + na * Ap;                                                                   // :246
+            z = r * di;
+            gp = r * z;
+            ok = reduce(2, gp, 0.0, 0.0, sums);
+            rz_prev = rz;
+            rz = sums[0];
+            g_old = rz_prev; a_old = a;
         }
-        g_old = gamma; a_old = alpha; pAp = delta;
-        ++iters;
-        const double na = -alpha;
-        s = first ? w : w + beta * s;
-        r = r + na * s;
-        const double zn = r * di;
-        ++seq;
-        publish(zn);                 // (on its way before the rest of the update)
-        p = first ? z : z + beta * p;
-        x = x + alpha * p;
-        z = zn;
-        gp = r * z;
-    }
-    if (!done && ok) {               // the loop condition once more after the last iteration (:217, :273): r.z only.  Its number is
-        double sums[CGR_NV];         // the current version's: one above the last reduction's, so the slot parities alternate
-        reduce(2, gp, 0.0, 0.0, sums, seq);
-        rz_last = sums[0];
+        if (!done && ok) rz_last = rz;          // the loop condition once more after the last iteration (:217, :273)
+    } else {
+        // ---- the single-reduction form (kmcf_cg.hip: cg1_update_kernel): gamma = (r, z) and delta = (A z, z) at one point
+        publish(z);
+        for (int k = 1; k <= A.limit; ++k) {
+            const bool first = k == 1;
+            const double w = spmv(has_row ? z : 0.0);
+            double sums[CGR_NV];
+            ok = reduce(first ? 3 : 2, gp, z * w, bbp, sums);
+            if (!ok) break;
+            const double gamma = sums[0], delta = sums[1];
+            if (first) bb = sums[2];
+            const bool go = A.check_tol ? (gamma / bb > A.tol2) : true;
+            rz_last = gamma;
+            if (!go) { done = 1; break; }
+            double beta = 0.0, alpha;
+            if (first) alpha = gamma / delta;
+            else {
+                beta = gamma / g_old;
+                alpha = gamma / (delta - beta * gamma / a_old);
+            }
+            g_old = gamma; a_old = alpha; pAp = delta;
+            ++iters;
+            const double na = -alpha;
+            s = first ? w : w + beta * s;
+            r = r + na * s;
+            const double zn = r * di;
+            publish(zn);                 // (on its way before the rest of the update)
+            p = first ? z : z + beta * p;
+            x = x + alpha * p;
+            z = zn;
+            gp = r * z;
+        }
+        if (!done && ok) {               // the loop condition once more after the last iteration (:217, :273): r.z only
+            double sums[CGR_NV];
+            reduce(2, gp, 0.0, 0.0, sums);
+            rz_last = sums[0];
+        }
     }
 #ifdef KMCF_CGR_PROFILE
     if ((blockIdx.x == 0 || blockIdx.x == 17 || blockIdx.x == A.nblocks - 1) && (tid == 0 || tid == 64 || tid == 700))
@@ -684,7 +724,7 @@ int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks)
 
 // Enqueues one resident solve on the workspace (m->d_r: b in, r out; m->d_x: x0 in, x out; m->d_dinv), scalars into
 // m->d_S.  The caller synchronises and then calls kmcf_cgr_check.
-int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters)
+int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, bool classic)
 {
     kmcf_cgr *g = m->cgr;
     KMCF_CHECK(g && g->tpb > 0, KMCF_ERR_STATE, "kmcf_cgr_solve: the matrix has no resident plan");
@@ -694,7 +734,7 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     const int limit = fixed_iters > 0 ? fixed_iters : max_it;
     // sequence numbers are 32 bits in the LL words and must never repeat within the life of the buffers: well before
     // the counter could wrap, the buffers are cleared and the counter starts again
-    if (g->seq_bound + (unsigned long long)limit + 16 > 0xf0000000ull) {
+    if (g->seq_bound + 3ull * (unsigned long long)limit + 32 > 0xf0000000ull) {
         // (a group: every rank reaches this point in the same solve -- the bound advances identically -- and clears its
         // zones between two collectives: nobody still writes granules of the solve before, nobody publishes early)
         if (c->nranks > 1) {
@@ -717,7 +757,7 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
         }
         g->seq_bound = 0;
     }
-    g->seq_bound += (unsigned long long)limit + 8;
+    g->seq_bound += 3ull * (unsigned long long)limit + 16;          // (publications + reductions: at most three numbers per iteration)
     static const long long timeout_ms = getenv("KMCF_CGR_TIMEOUT_MS") ? atoll(getenv("KMCF_CGR_TIMEOUT_MS")) : 4000;
     int rate_khz = 0;
     KMCF_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
@@ -734,6 +774,7 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     A.timeout = (long long)rate_khz * timeout_ms;
     if (c->nranks > 1 && c->p2p && !getenv("KMCF_CGR_TIMEOUT_MS")) A.timeout = c->p2p->timeout_ticks;      // (a group: the transport's bound, KMCF_P2P_TIMEOUT_MS)
     A.limit = limit; A.check_tol = fixed_iters > 0 ? 0 : 1; A.tol2 = tol * tol;
+    A.classic = classic ? 1 : 0;
     A.sibling_lds = !(getenv("KMCF_CGR_SIB") && atoi(getenv("KMCF_CGR_SIB")) == 0);
     A.nranks = c->nranks; A.rank = c->rank; A.n_loc = m->n_loc;
     if (c->nranks > 1) {

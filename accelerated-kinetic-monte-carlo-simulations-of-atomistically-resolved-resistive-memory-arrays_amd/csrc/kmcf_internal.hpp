@@ -135,6 +135,7 @@ struct kmcf_matrix {
     unsigned int *d_long_ctr = nullptr;
     kmcf_subop *sub = nullptr;         // optional: y[sub rows] += S x_sub after the CSR part (T matrix)
     kmcf_p2p_halo *p2p = nullptr;      // halo landing zone / flags in the peer windows (p2p transport)
+    bool last_solve_resident = false;  // the solve enqueued last ran as ONE resident launch (its scalars are complete: no tail for the output kernel to form)
     struct kmcf_cgr *cgr = nullptr;    // plan and buffers of the register-resident solve (kmcf_cgr.hip); tpb == 0: does not qualify
     int row0 = 0;                 // displs[rank]
     int64_t nnz = 0;
@@ -429,10 +430,16 @@ int kmcf_p2p_direct_put(kmcf_matrix *m, unsigned long long seq, bool skip_if_don
 int kmcf_p2p_direct_ack(kmcf_matrix *m, unsigned long long seq, bool skip_if_done);      // standalone acknowledgement (compute stream)
 // cgr.hip: register-resident PCG (one launch per solve) for matrices whose tiles are all resident at once
 bool kmcf_cgr_usable(kmcf_matrix *m);
-int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters);
+int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, bool classic);
 int kmcf_cgr_check(kmcf_matrix *m);           // after the synchronisation: KMCF_ERR_STATE if a bounded wait expired
 int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks);
 void kmcf_cgr_free(kmcf_matrix *m);
+// the reference's recurrence runs as a resident launch only on small matrices (kmcf_cg.hip: pcg_workspace_run)
+inline bool kmcf_cgr_classic_applies(const kmcf_matrix *m)
+{
+    static const int classic_tiles = getenv("KMCF_CGR_CLASSIC_TILES") ? atoi(getenv("KMCF_CGR_CLASSIC_TILES")) : 512;
+    return m->comm->nranks == 1 && !m->comm->force_collectives && m->n_sell_tiles <= classic_tiles;
+}
 // matrix.hip
 int kmcf_matrix_build(kmcf_comm *c, int matrix_size, const int *counts, const int *displs,
                       const int *h_row_ptr, const int *h_col_global, const double *h_val,

@@ -1791,7 +1791,8 @@ extern "C" int kmcf_matrix_sum_plan(const kmcf_matrix *m, kmcf_sum_plan_t *plan,
         plan->long_items = m->n_long_items;
         plan->sub_grid = m->sub ? m->sub->grid : 0;
         plan->cg_variant = kmcf_cg_single_reduction(m) ? 1 : 0;
-        if (plan->cg_variant == 1) kmcf_cgr_plan_info(const_cast<kmcf_matrix *>(m), &plan->resident_tpb, &plan->resident_g1, nullptr);
+        if (plan->cg_variant == 1 || (m->comm->nranks == 1 && kmcf_cgr_classic_applies(m)))   // (the reference's recurrence: one rank, small matrices)
+            kmcf_cgr_plan_info(const_cast<kmcf_matrix *>(m), &plan->resident_tpb, &plan->resident_g1, nullptr);
     }
     KMCF_HIP(hipSetDevice(m->comm->device));
     KMCF_HIP(hipStreamSynchronize(m->comm->stream));

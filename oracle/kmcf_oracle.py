@@ -218,6 +218,10 @@ def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode
                                             C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
         L.orc_spmv_device_order.argtypes = [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L.orc_pcg_resident_order.restype = C.c_int
+        L.orc_pcg_resident_order.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
         L.orc_pcg1_resident_order.restype = C.c_int
         L.orc_pcg1_resident_order.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_double),
@@ -234,14 +238,18 @@ def pcg_device_order(plan, rhs, x0, dinv, tol, max_it, fixed_iters=0, check_mode
     hist = np.zeros(max(int(max_it), int(fixed_iters)) + 2) if history else None
     # variant: the recurrence the library runs on this matrix (plan["cg_variant"]: 0 classic = the reference's
     # operation order, 1 single-reduction) unless the caller names one
-    # ("cg1r-loop": the single-reduction recurrence as the two kernels per iteration of pcg1_loop even where the plan
-    # names a resident launch)
+    # ("cg1r-loop" / "classic-loop": the recurrence as the loop of kernels even where the plan names a resident launch)
     cg1r = plan["cg_variant"] == 1 if variant is None else variant in ("cg1r", "cg1r-loop")
     common = (n, _i(plan["row_ptr"]), _i(plan["col"]), _f(plan["val"] if val is None else val), r, x, dv,
               1 if dinv is not None else 0, float(tol), int(max_it), int(fixed_iters))
     tail = (int(plan["vec_grid"]), int(plan["sell_grid"]), len(plan["tile_first"]), _i(plan["tile_first"]),
             _i(plan["tile_rows"]), C.byref(bb), C.byref(rz), C.byref(done), hist.ctypes.data_as(C.c_void_p) if history else None)
-    if cg1r and plan.get("resident_tpb", 0) > 0 and variant != "cg1r-loop":
+    resident = plan.get("resident_tpb", 0) > 0 and variant not in ("cg1r-loop", "classic-loop")
+    if resident and not cg1r:
+        # the reference's recurrence as ONE register-resident launch: every dot over the resident tree
+        assert check_mode == 1
+        it = L.orc_pcg_resident_order(*common, int(plan["resident_tpb"]), int(plan["resident_g1"]), *tail[2:])
+    elif cg1r and resident:
         # the single-reduction recurrence as ONE register-resident launch (csrc/kmcf_cgr.hip): its own reduction tree
         assert check_mode == 1
         it = L.orc_pcg1_resident_order(*common, int(plan["resident_tpb"]), int(plan["resident_g1"]), *tail[2:])

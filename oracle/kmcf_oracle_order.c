@@ -444,6 +444,80 @@ int orc_pcg1_resident_order(int n, const int *rp, const int *col, const double *
     return iters;
 }
 
+/* The reference's recurrence (orc_pcg_device_order above: :217-266, p.Ap and r.z reduced separately) as ONE register-resident
+ * launch (csrc/kmcf_cgr.hip, classic = 1): rows and row sums as the row-per-lane kernel's, every dot product over the
+ * resident tree (resident_sum), x += alpha p applied where alpha is formed (the kernels apply it one kernel later: the same
+ * operation on the same operands).  Arguments as orc_pcg1_resident_order. */
+int orc_pcg_resident_order(int n, const int *rp, const int *col, const double *val, double *r, double *x, const double *dinv,
+                           int precond, double tol, int max_it, int fixed_iters, int tpb, int g1, int n_tiles,
+                           const int *tile_first, const int *tile_rows, double *bb_out, double *rz_out, int *done_out,
+                           double *rz_hist)
+{
+    double *z = (double *)malloc(((size_t)n + 1) * sizeof(double));
+    double *w = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *p = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *la = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    double *lc = (double *)calloc((size_t)n_tiles * BLK, sizeof(double));
+    const double tol2 = tol * tol;
+#define FOR_LANES(...)                                                           \
+    for (int c = 0; c < n_tiles; ++c)                                            \
+        for (int t = 0; t < tile_rows[c]; ++t) {                                 \
+            const int i = tile_first[c] + t;                                     \
+            const size_t L = (size_t)c * BLK + t;                                \
+            __VA_ARGS__                                                          \
+        }
+    for (int i = 0; i < n; ++i) w[i] = row_sum_diag_last(i, rp, col, val, x);                 /* A x0 */
+    FOR_LANES({
+        const double b = r[i];
+        lc[L] = b * b;
+        const double ri = b + (-1.0) * w[i];
+        r[i] = ri;
+        z[i] = ri * (precond ? dinv[i] : 1.0);
+        la[L] = ri * z[i];
+    })
+    double rz = resident_sum(la, n_tiles, tpb, g1);
+    const double bb = resident_sum(lc, n_tiles, tpb, g1);
+    double rz_prev = 0.0, rz_last = 0.0;
+    int iters = 0, done = 0;
+    const int limit = fixed_iters > 0 ? fixed_iters : max_it;
+    for (int k = 1; k <= limit; ++k) {
+        const int first = k == 1;
+        const int go = fixed_iters > 0 ? 1 : (rz / bb > tol2);
+        rz_last = rz;
+        if (rz_hist) rz_hist[k - 1] = rz;
+        if (!go) { done = 1; break; }
+        iters += 1;
+        if (first) { for (int i = 0; i < n; ++i) p[i] = z[i]; }
+        else {
+            const double beta = rz / rz_prev;
+            for (int i = 0; i < n; ++i) p[i] = beta * p[i] + z[i];
+        }
+        for (int i = 0; i < n; ++i) w[i] = row_sum_diag_last(i, rp, col, val, p);
+        FOR_LANES({ la[L] = p[i] * w[i]; })
+        const double pAp = resident_sum(la, n_tiles, tpb, g1);
+        const double a = rz / pAp, na = -a;
+        FOR_LANES({
+            x[i] = x[i] + a * p[i];
+            const double ri = r[i] + na * w[i];
+            r[i] = ri;
+            z[i] = ri * (precond ? dinv[i] : 1.0);
+            la[L] = ri * z[i];
+        })
+        rz_prev = rz;
+        rz = resident_sum(la, n_tiles, tpb, g1);
+    }
+    if (!done) {
+        rz_last = rz;
+        if (rz_hist) rz_hist[limit] = rz;
+    }
+#undef FOR_LANES
+    *bb_out = bb;
+    *rz_out = rz_last;
+    *done_out = done;
+    free(z); free(w); free(p); free(la); free(lc);
+    return iters;
+}
+
 /* Pieces of the register-resident solve for groups of ranks (csrc/kmcf_cgr.hip with nranks > 1), driven rank by rank
  * from kmcf_oracle.py: pcg_resident_ranks.  Row sums over a rank's rows with xv = [own | halo] (every row, boundary
  * rows included, is added like the row-per-lane kernel adds it); a rank's sum of one value per row over its tiles,

@@ -44,6 +44,7 @@ print("RESULT " + json.dumps(dict(st=st, vsum=float(np.abs(v).sum()), charged=in
 def _run(force):
     env = dict(os.environ)
     env.pop("KMCF_FORCE_COMM", None)
+    env["KMCF_CG_RESIDENT"] = "0"      # both runs as the loop of kernels (the plain one would otherwise be ONE resident launch, which adds in another order)
     if force:
         env["KMCF_FORCE_COMM"] = "1"
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)

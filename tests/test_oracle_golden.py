@@ -226,5 +226,15 @@ def test_resident_order_restatement_is_the_same_recurrence(oracle, ref5):
         assert a["converged"] and abs(a["iterations"] - b["iterations"]) <= 0.05 * b["iterations"]
         assert np.abs(a["x"] - ref5["x"]).max() <= 5e-4
         assert np.sqrt(a["rz"] / a["bb"]) <= ref5["tol"]
+    # the reference's recurrence (two reduction points) over the resident tree against the same recurrence as the loop of kernels
+    cl = dict(base, cg_variant=0)
+    c40 = oracle.pcg_device_order(dict(cl, resident_tpb=2, resident_g1=0), A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 40)
+    l40 = oracle.pcg_device_order(dict(cl, resident_tpb=0, resident_g1=0), A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 40)
+    assert c40["iterations"] == l40["iterations"] == 40 and np.abs(c40["x"] - l40["x"]).max() <= 1e-9
+    cc = oracle.pcg_device_order(dict(cl, resident_tpb=2, resident_g1=0), A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 10000)
+    assert cc["converged"] and abs(cc["iterations"] - ref5["iters"]) <= 0.05 * ref5["iters"] and np.abs(cc["x"] - ref5["x"]).max() <= 5e-4
+    # fixed iteration count: exactly that many, the residual after the last one reported
+    cf = oracle.pcg_device_order(dict(cl, resident_tpb=2, resident_g1=0), A["rhs"], np.zeros(n), A["dinv"], ref5["tol"], 10000, fixed_iters=7)
+    assert cf["iterations"] == 7 and not cf["converged"]
     # the two trees are different computations: not bit-identical (or the test would prove nothing about the tree)
     assert not np.array_equal(out["tpb4"][1]["x"], out["loop"][1]["x"]) or not np.array_equal(out["tpb1"][1]["x"], out["loop"][1]["x"])

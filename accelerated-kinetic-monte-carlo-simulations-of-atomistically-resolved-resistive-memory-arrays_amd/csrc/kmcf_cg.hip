@@ -824,6 +824,12 @@ static int pcg_resident(kmcf_matrix *m, bool precond, double tol, int max_it, in
     return pcg_collect(m, tol * tol, 0, stats);
 }
 
+bool kmcf_pcg_resident_applies(kmcf_matrix *m)
+{
+    if (kmcf_cg_single_reduction(m)) return kmcf_cgr_usable(m);
+    return kmcf_cgr_classic_applies(m) && kmcf_cgr_usable(m);
+}
+
 static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, kmcf_solve_stats_t *stats, int flags)
 {
     m->last_solve_resident = false;
@@ -831,6 +837,7 @@ static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_i
     // cg1r = single-reduction variant (default for multi-rank groups)
     if (kmcf_cg_single_reduction(m)) {
         if (kmcf_cgr_usable(m) && (fixed_iters > 0 || max_it > 0)) return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags, false);
+        KMCF_CHECK(!m->solve_x_user && !m->solve_b_src, KMCF_ERR_STATE, "solve set up for a resident launch that does not apply");
         if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
         return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }
@@ -840,6 +847,7 @@ static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_i
     // tiles: 16.3 / 14.8) -- up to 512 tiles (KMCF_CGR_CLASSIC_TILES)
     if (kmcf_cgr_classic_applies(m) && (fixed_iters > 0 || max_it > 0) && kmcf_cgr_usable(m))
         return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags, true);
+    KMCF_CHECK(!m->solve_x_user && !m->solve_b_src, KMCF_ERR_STATE, "solve set up for a resident launch that does not apply");
     if (precond) return pcg_loop<true>(m, tol, max_it, fixed_iters, 0, stats, flags);
     return pcg_loop<false>(m, tol, max_it, fixed_iters, 0, stats, flags);
 }

@@ -68,6 +68,9 @@ struct cgr_args {
     const double *dict, *diagv;
     double *r, *x;
     const double *dinv;              // nullptr: unpreconditioned
+    const double *b_src;             // right-hand side (internal order); r receives the residual
+    double *x_user;                  // nullptr, or: start guess in / solution out in the caller's order (through perm), instead of x
+    const int *perm;                 // internal row -> caller's row (nullptr: identity)
     kmcf_scalars *S;
     u64 *zll;
     long long zwords;                // words per parity buffer
@@ -208,8 +211,9 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     for (int k = 0; k < ND; ++k) dv[k] = A.dict[k];
     const double dg = has_row ? A.diagv[row] : 0.0;
     const double di = has_row ? (A.dinv ? A.dinv[row] : 1.0) : 0.0;
-    const double b_i = has_row ? A.r[row] : 0.0;
-    double x = has_row ? A.x[row] : 0.0;
+    const double b_i = has_row ? A.b_src[row] : 0.0;
+    const int urow = has_row && A.x_user ? (A.perm ? A.perm[row] : row) : 0;
+    double x = has_row ? (A.x_user ? A.x_user[urow] : A.x[row]) : 0.0;
     unsigned int seq = *A.seq;                   // (read by every block before block 0 overwrites it at the very end)
     // Every publication and every reduction takes the next sequence number (unique over the life of the buffers); which
     // of its two buffers a publication / a reduction uses alternates on its own count (zpar / rpar), the same in every
@@ -540,7 +544,11 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                (int)blockIdx.x, tid, iters, (double)tp_gather / max(iters, 1), (double)tp_row / max(iters, 1), (double)tp_red1 / max(iters, 1),
                (double)tp_red2 / max(iters, 1), (double)tp_red3 / max(iters, 1));
 #endif
-    if (has_row) { A.x[row] = x; A.r[row] = r; }
+    if (has_row) {
+        if (A.x_user) A.x_user[urow] = x;
+        else A.x[row] = x;
+        A.r[row] = r;
+    }
     if (blockIdx.x == 0 && tid == 0) {
         kmcf_scalars h;
         h.bb = bb; h.rz[0] = h.rz[1] = g_old; h.rz_last = rz_last; h.pAp = pAp;
@@ -767,6 +775,9 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     A.stream = reinterpret_cast<const sell_pair *>(m->d_sell);
     A.dict = m->d_dict; A.diagv = m->d_diagv;
     A.r = m->d_r; A.x = m->d_x; A.dinv = precond ? m->d_dinv : nullptr;
+    A.b_src = m->solve_b_src ? m->solve_b_src : m->d_r;
+    A.x_user = m->solve_x_user;
+    A.perm = m->d_perm;
     A.S = m->d_S;
     A.zll = g->d_zll; A.zwords = (long long)g->zwords;
     A.slot = g->d_slot; A.gslot = g->d_gslot; A.seq = g->d_seq;

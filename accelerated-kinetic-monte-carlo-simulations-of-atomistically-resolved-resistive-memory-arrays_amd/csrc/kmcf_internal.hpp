@@ -135,6 +135,11 @@ struct kmcf_matrix {
     unsigned int *d_long_ctr = nullptr;
     kmcf_subop *sub = nullptr;         // optional: y[sub rows] += S x_sub after the CSR part (T matrix)
     kmcf_p2p_halo *p2p = nullptr;      // halo landing zone / flags in the peer windows (p2p transport)
+    // optional, for the length of one kmcf_pcg_workspace call that runs resident (kmcf_pcg_resident_applies): the right-hand
+    // side where it lies (internal order, read-only) instead of d_r, and the start guess / solution in the CALLER's order and
+    // place instead of d_x -- the K solve of a KMC step then needs no copy and no permuting kernel around its one launch
+    const double *solve_b_src = nullptr;
+    double *solve_x_user = nullptr;
     bool last_solve_resident = false;  // the solve enqueued last ran as ONE resident launch (its scalars are complete: no tail for the output kernel to form)
     struct kmcf_cgr *cgr = nullptr;    // plan and buffers of the register-resident solve (kmcf_cgr.hip); tpb == 0: does not qualify
     int row0 = 0;                 // displs[rank]
@@ -431,6 +436,7 @@ int kmcf_p2p_direct_ack(kmcf_matrix *m, unsigned long long seq, bool skip_if_don
 // cgr.hip: register-resident PCG (one launch per solve) for matrices whose tiles are all resident at once
 bool kmcf_cgr_usable(kmcf_matrix *m);
 int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fixed_iters, bool classic);
+bool kmcf_pcg_resident_applies(kmcf_matrix *m);      // kmcf_cg.hip: the next kmcf_pcg_workspace call on m runs as a resident launch
 int kmcf_cgr_check(kmcf_matrix *m);           // after the synchronisation: KMCF_ERR_STATE if a bounded wait expired
 int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks);
 void kmcf_cgr_free(kmcf_matrix *m);

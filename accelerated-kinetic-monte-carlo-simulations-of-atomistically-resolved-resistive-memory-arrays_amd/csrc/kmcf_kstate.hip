@@ -645,12 +645,20 @@ extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_sit
     const size_t bytes = (size_t)m->n_loc * sizeof(double);
     // the initial guess is the current potential inside the device, solved in place (:861)
     double *v_soln = d_site_potential_boundary + N_left_tot + m->row0;
-    KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));   // internal order already
-    KMCF_TRY(kmcf_vec_in(m, m->d_x, v_soln));
     const double relative_tolerance = 1e-14 * k->N_interface;   // :885
     const int max_iterations = 10000;                           // :886
-    KMCF_TRY(kmcf_pcg_workspace(m, true, relative_tolerance, max_iterations, 0, stats));
-    KMCF_TRY(kmcf_vec_out(m, v_soln, m->d_x));
+    // a solve that runs as ONE resident launch (kmcf_cgr.hip) takes the right-hand side where the assembly left it and
+    // the start guess / solution in the caller's array: no copy, no permuting kernel around it
+    const bool direct = m->n_loc > 0 && kmcf_pcg_resident_applies(m);
+    if (direct) { m->solve_b_src = k->d_rhs; m->solve_x_user = v_soln; }
+    else {
+        KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));   // internal order already
+        KMCF_TRY(kmcf_vec_in(m, m->d_x, v_soln));
+    }
+    const int rc_solve = kmcf_pcg_workspace(m, true, relative_tolerance, max_iterations, 0, stats);
+    m->solve_b_src = nullptr; m->solve_x_user = nullptr;
+    KMCF_TRY(rc_solve);
+    if (!direct) KMCF_TRY(kmcf_vec_out(m, v_soln, m->d_x));
     KMCF_HIP(hipStreamSynchronize(c->stream));
     if (stats) {
         float ms = 0.f;

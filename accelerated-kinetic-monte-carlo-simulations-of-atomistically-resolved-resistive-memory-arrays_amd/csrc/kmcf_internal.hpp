@@ -355,6 +355,16 @@ struct kmcf_subop {
     int *d_strip_first = nullptr;            // nb + 1: first strip of every block row
     double *d_rowpart = nullptr, *d_colpart = nullptr;   // 2 x 64 per strip / 2 x 64 per tile (the power pass needs two sums)
     size_t cap_tiles = 0, cap_strips = 0, cap_sf = 0, cap_rowpart = 0, cap_colpart = 0;
+    // ... spread over a rank group (round 4): the strips of the upper block triangle dealt to the ranks (each strip of the
+    // global list -- block rows ascending, then columns -- to the rank holding the fewest tiles so far, the lowest such
+    // rank; n_strips / n_tiles / d_strips / d_tiles then count and hold THIS rank's), every rank forms its partial of ALL 64 nb sums, the partials are all-gathered and added in rank order
+    // by the owner of each point (sub_combine_kernel).  One more all-gather per application than the row-sliced bitmap
+    // form -- for half the bytes per entry and the tile kernel's rate.
+    bool spread = false;
+    int *d_tile_local = nullptr;             // global tile index -> this rank's tile, -1: another rank's
+    double *d_ypart = nullptr;               // P x (1 or 2) x 64 nb: every rank's partial sums (rank q's at q W 64 nb)
+    long long n_tiles_glob = 0;
+    size_t cap_tile_local = 0, cap_ypart = 0;
     // ... or (jagged, with dense set: strips, parts and their reduction are shared) the same tiles holding only their
     // ENTRIES: tile-major row masks + the values in layers (kmcf_tstate.hip: sub_symj_kernel) -- 4 B per entry of the
     // full block + 1 bit per position instead of 4 B per position

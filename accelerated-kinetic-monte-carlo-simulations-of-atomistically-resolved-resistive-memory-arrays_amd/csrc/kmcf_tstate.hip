@@ -64,6 +64,7 @@ struct kmcf_tstate {
     double *d_scal = nullptr;                      // [0] imacro, [1] min
     int *d_err = nullptr;
     int *h_pin = nullptr;                          // pinned: [0] n_t, [1] err, [2..3] nnz (long long)
+    double *d_agree = nullptr, *h_agree = nullptr; // storage vote of a rank group: 2 P on the device; pinned 2 + 2 P
     bool assembled = false;
     kmcf_current_params_t par{};
 };
@@ -1050,8 +1051,12 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_reduce_kernel(int n_glob,
                                                                      const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                                      const int *__restrict__ rows, const double *__restrict__ p,
                                                                      double *__restrict__ y, double *__restrict__ y2, double *__restrict__ part,
-                                                                     const kmcf_scalars *__restrict__ S, int check_done)
+                                                                     const kmcf_scalars *__restrict__ S, int check_done,
+                                                                     const int *__restrict__ tile_local = nullptr, double *__restrict__ ypart = nullptr)
 {
+    // Spread over a rank group (tile_local, ypart != nullptr): the same walk over THIS rank's tiles and strips (another
+    // rank's tile (K, B) is skipped in place: wave w keeps K = w, w + 4, ...; the strips are this rank's list), the sums
+    // of all 64 nb points go to ypart (and ypart + 64 nb, MODE 1) for sub_combine_kernel instead of y.
     __shared__ double sh[2][2][4][64];                  // [a / b][column / row parts][wave][lane]
     __shared__ double lds4[4];
     if (check_done && S->done) return;
@@ -1060,7 +1065,12 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_reduce_kernel(int n_glob,
     double ca = 0.0, cb = 0.0, ra = 0.0, rb = 0.0;
 #pragma unroll 4
     for (int K = w; K < B; K += 4) {
-        const size_t t = (size_t)symm_tile_index(nb, K, B);
+        size_t t = (size_t)symm_tile_index(nb, K, B);
+        if (tile_local) {
+            const int tl = tile_local[t];
+            if (tl < 0) continue;
+            t = (size_t)tl;
+        }
         ca += colpart[t * W + l];
         if (MODE == 1) cb += colpart[t * W + 64 + l];
     }
@@ -1073,6 +1083,16 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_reduce_kernel(int n_glob,
     __syncthreads();
     double dot = 0.0;
     const int i = 64 * B + l;
+    if (ypart) {
+        if (w == 0) {
+            ypart[i] = ((sh[0][0][0][l] + sh[0][0][1][l]) + (sh[0][0][2][l] + sh[0][0][3][l])) +
+                       ((sh[0][1][0][l] + sh[0][1][1][l]) + (sh[0][1][2][l] + sh[0][1][3][l]));
+            if (MODE == 1)
+                ypart[64 * nb + i] = ((sh[1][0][0][l] + sh[1][0][1][l]) + (sh[1][0][2][l] + sh[1][0][3][l])) +
+                                     ((sh[1][1][0][l] + sh[1][1][1][l]) + (sh[1][1][2][l] + sh[1][1][3][l]));
+        }
+        return;
+    }
     if (w == 0 && i < n_glob) {
         const double a = ((sh[0][0][0][l] + sh[0][0][1][l]) + (sh[0][0][2][l] + sh[0][0][3][l])) +
                          ((sh[0][1][0][l] + sh[0][1][1][l]) + (sh[0][1][2][l] + sh[0][1][3][l]));
@@ -1092,15 +1112,49 @@ __global__ __launch_bounds__(KMCF_BLOCK) void sub_symm_reduce_kernel(int n_glob,
     }
 }
 
-// tdiag = -(row sums), the diagonal entries of the diagonal tiles (calc_diagonal_T_tunnel, :669-689)
+// The sums of a rank group's partials (spread storage): point row0 + s = the partials of ranks 0, 1, ... in that order;
+// into y[rows[s]] (rows == nullptr: y[s]) and y2 (MODE 1); fused p.Ap partial, one per block of 256 points (MODE 0).
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(KMCF_BLOCK) void sub_combine_kernel(int ns, int row0, int P, int npad, const double *__restrict__ ypart_all,
+                                                                 const int *__restrict__ rows, const double *__restrict__ p,
+                                                                 double *__restrict__ y, double *__restrict__ y2, double *__restrict__ part,
+                                                                 const kmcf_scalars *__restrict__ S, int check_done)
+{
+    __shared__ double lds4[4];
+    if (check_done && S->done) return;
+    constexpr int W = MODE == 0 ? 1 : 2;
+    const int s = blockIdx.x * KMCF_BLOCK + threadIdx.x;
+    double dot = 0.0;
+    if (s < ns) {
+        const size_t i = (size_t)row0 + s;
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < P; ++q) {
+            a += ypart_all[(size_t)q * W * npad + i];
+            if (MODE == 1) b += ypart_all[(size_t)q * W * npad + npad + i];
+        }
+        const int r = rows ? rows[s] : s;
+        y[r] += a;
+        if (MODE == 1) y2[r] += b;
+        else if (DOT) dot = p[r] * a;
+    }
+    if (DOT) {
+        const double t = block_sum4(dot, lds4);
+        if (threadIdx.x == 0) part[blockIdx.x] = t;
+    }
+}
+
+// tdiag = -(row sums), the diagonal entries of the diagonal tiles (calc_diagonal_T_tunnel, :669-689); tile_local: the
+// spread storage's map (only this rank's diagonal tiles exist here)
 __global__ __launch_bounds__(KMCF_BLOCK) void symm_set_diag_kernel(int n_glob, int nb, const double *__restrict__ rowsum, double *__restrict__ tdiag,
-                                                                   double *__restrict__ tiles)
+                                                                   double *__restrict__ tiles, const int *__restrict__ tile_local)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_glob; i += gridDim.x * blockDim.x) {
         const double d = -rowsum[i];
         tdiag[i] = d;
         const int B = i >> 6, l = i & 63;
-        tiles[(size_t)symm_tile_index(nb, B, B) * 4096 + l * 64 + l] = d;
+        long long tl = symm_tile_index(nb, B, B);
+        if (tile_local) tl = tile_local[tl];
+        if (tl >= 0) tiles[(size_t)tl * 4096 + l * 64 + l] = d;
     }
 }
 
@@ -1148,10 +1202,11 @@ extern "C" int kmcf_tstate_destroy(kmcf_tstate *t)
                         t->d_tflag, t->d_blk, t->d_tidx, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->d_rowcnt, t->d_tdiag,
                         t->sub.d_rows, t->sub.d_mask, t->sub.d_voff, t->sub.d_val, t->sub.d_xsub, t->d_pdisp, t->d_scal, t->d_err,
                         t->sub.d_tiles, t->sub.d_strips, t->sub.d_strip_first, t->sub.d_rowpart, t->sub.d_colpart,
-                        t->sub.d_jmask, t->sub.d_jvoff, t->sub.d_jval, t->sub.d_jcnt};
+                        t->sub.d_jmask, t->sub.d_jvoff, t->sub.d_jval, t->sub.d_jcnt, t->sub.d_tile_local, t->sub.d_ypart, t->d_agree};
         for (void *p : ptrs)
             if (p) hipFree(p);
         if (t->h_pin) hipHostFree(t->h_pin);
+        if (t->h_agree) hipHostFree(t->h_agree);
     }
     if (t->T) { t->T->sub = nullptr; kmcf_matrix_destroy(t->T); }
     delete t;
@@ -1318,6 +1373,10 @@ extern "C" int kmcf_initialize_sparsity_T(kmcf_comm *c, const double *d_site_x, 
     KMCF_TRY(dalloc(&t->d_tcb, (size_t)Na));
     KMCF_TRY(dalloc(&t->d_pdisp, (size_t)Nsub + 2)); KMCF_TRY(dalloc(&t->d_scal, 4)); KMCF_TRY(dalloc(&t->d_err, 1));
     KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_pin), 8 * sizeof(int), hipHostMallocDefault));
+    memset(t->h_pin, 0, 8 * sizeof(int));
+    KMCF_TRY(dalloc(&t->d_agree, (size_t)2 * P));
+    KMCF_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_agree), (size_t)(2 + 2 * P) * sizeof(double), hipHostMallocDefault));
+    memset(t->h_agree, 0, (size_t)(2 + 2 * P) * sizeof(double));
     t->sub.counts.assign(P, 0);
     t->sub.displs.assign(P, 0);
     guard.t = nullptr;
@@ -1381,34 +1440,80 @@ static int symm_launch(kmcf_subop &sb, const double *x, double Vd, hipStream_t s
     return KMCF_OK;
 }
 
-// strips, tiles, values, diagonal of the dense symmetric storage (one rank; after the tunnel points are known)
+// Spread storage: this rank's partial sums -> every rank's partials (one all-gather on the compute stream) -> the sums
+// of the ns points from row0 on, added in rank order (MODE / DOT / rows / y / y2 / part as in sub_symm_reduce_kernel).
+// Every rank of the group calls it, also one without points of its own (ns == 0): it holds strips like the others.
+template <int MODE, bool DOT>
+static int symm_spread_finish(kmcf_comm *c, kmcf_subop &sb, int ns, int row0, const int *rows, const double *p, double *y, double *y2,
+                              double *part, const kmcf_scalars *S, int chk)
+{
+    hipStream_t st = c->stream;
+    constexpr int W = MODE == 0 ? 1 : 2;
+    const int P = c->nranks, npad = 64 * sb.nb;
+    sub_symm_reduce_kernel<MODE, false><<<sb.nb, KMCF_BLOCK, 0, st>>>(sb.n_glob, sb.nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart, nullptr, nullptr,
+                                                                      nullptr, nullptr, nullptr, S, chk, sb.d_tile_local,
+                                                                      sb.d_ypart + (size_t)c->rank * W * npad);
+    KMCF_HIP(hipGetLastError());
+    std::vector<int> cnt((size_t)P, W * npad), dsp((size_t)P);
+    for (int q = 0; q < P; ++q) dsp[q] = q * W * npad;
+    KMCF_TRY(kmcf_comm_allgatherv_double(c, sb.d_ypart, cnt.data(), dsp.data()));
+    if (ns > 0) {
+        sub_combine_kernel<MODE, DOT><<<(ns + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(ns, row0, P, npad, sb.d_ypart, rows, p, y, y2, part, S, chk);
+        KMCF_HIP(hipGetLastError());
+    }
+    return KMCF_OK;
+}
+
+// strips, tiles, values, diagonal of the dense symmetric storage (after the tunnel points are known): of one rank, or
+// (sb.spread) this rank's share of a group's
 static int symm_setup(kmcf_tstate *t)
 {
     kmcf_subop &sb = t->sub;
-    hipStream_t st = t->comm->stream;
+    kmcf_comm *c = t->comm;
+    hipStream_t st = c->stream;
     const kmcf_current_params_t *p = &t->par;
     const int n_t = sb.n_glob, nb = (n_t + 63) / 64;
+    const int P = sb.spread ? c->nranks : 1, rank = sb.spread ? c->rank : 0;
     sb.nb = nb;
-    sb.n_tiles = (long long)nb * (nb + 1) / 2;
+    sb.n_tiles_glob = (long long)nb * (nb + 1) / 2;
+    KMCF_CHECK(sb.n_tiles_glob < (long long)INT32_MAX, KMCF_ERR_ARG, "tunnel block of %d points: tile index exceeds int32", n_t);
     int strip_len = 16;
     if (const char *e = getenv("KMCF_SUB_STRIP")) strip_len = std::max(1, atoi(e));
     std::vector<int4> strips;
-    std::vector<int> first((size_t)nb + 1, 0);
+    std::vector<int> first((size_t)nb + 1, 0), tile_local;
+    if (sb.spread) tile_local.assign((size_t)sb.n_tiles_glob, -1);
+    // the deal: strip after strip (block rows ascending, then columns) to the rank that holds the fewest tiles so far,
+    // the lowest such rank -- within a strip's length of even, whatever the mix of full and ragged strips
+    std::vector<long long> held((size_t)P, 0);
+    long long n_mine = 0;
     for (int I = 0; I < nb; ++I) {
         first[I] = (int)strips.size();
-        for (int J = I; J < nb; J += strip_len)
-            strips.push_back(make_int4(I, J, std::min(strip_len, nb - J), (int)symm_tile_index(nb, I, J)));
+        for (int J = I; J < nb; J += strip_len) {
+            const int len = std::min(strip_len, nb - J);
+            const int owner = (int)(std::min_element(held.begin(), held.end()) - held.begin());
+            held[owner] += len;
+            if (owner != rank) continue;
+            strips.push_back(make_int4(I, J, len, (int)(sb.spread ? n_mine : symm_tile_index(nb, I, J))));
+            if (sb.spread)
+                for (int q = 0; q < len; ++q) tile_local[(size_t)symm_tile_index(nb, I, J + q)] = (int)(n_mine + q);
+            n_mine += len;
+        }
     }
     first[nb] = (int)strips.size();
-    KMCF_CHECK(sb.n_tiles < (long long)INT32_MAX, KMCF_ERR_ARG, "tunnel block of %d points: tile index exceeds int32", n_t);
+    sb.n_tiles = n_mine;
     sb.n_strips = (int)strips.size();
-    if (!sb.jagged) KMCF_TRY(ensure(&sb.d_tiles, &sb.cap_tiles, (size_t)sb.n_tiles * 4096));
-    KMCF_TRY(ensure(&sb.d_strips, &sb.cap_strips, strips.size()));
+    if (!sb.jagged) KMCF_TRY(ensure(&sb.d_tiles, &sb.cap_tiles, (size_t)std::max<long long>(sb.n_tiles, 1) * 4096));
+    KMCF_TRY(ensure(&sb.d_strips, &sb.cap_strips, strips.size() + 1));
     KMCF_TRY(ensure(&sb.d_strip_first, &sb.cap_sf, first.size()));
-    KMCF_TRY(ensure(&sb.d_rowpart, &sb.cap_rowpart, (size_t)sb.n_strips * 128));
-    KMCF_TRY(ensure(&sb.d_colpart, &sb.cap_colpart, (size_t)sb.n_tiles * 128));
-    KMCF_HIP(hipMemcpyAsync(sb.d_strips, strips.data(), strips.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+    KMCF_TRY(ensure(&sb.d_rowpart, &sb.cap_rowpart, (size_t)(sb.n_strips + 1) * 128));
+    KMCF_TRY(ensure(&sb.d_colpart, &sb.cap_colpart, (size_t)std::max<long long>(sb.n_tiles, 1) * 128));
+    if (!strips.empty()) KMCF_HIP(hipMemcpyAsync(sb.d_strips, strips.data(), strips.size() * sizeof(int4), hipMemcpyHostToDevice, st));
     KMCF_HIP(hipMemcpyAsync(sb.d_strip_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (sb.spread) {
+        KMCF_TRY(ensure(&sb.d_tile_local, &sb.cap_tile_local, tile_local.size() + 1));
+        KMCF_TRY(ensure(&sb.d_ypart, &sb.cap_ypart, (size_t)2 * P * 64 * nb));
+        KMCF_HIP(hipMemcpyAsync(sb.d_tile_local, tile_local.data(), tile_local.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
     KMCF_HIP(hipStreamSynchronize(st));                            // (the host vectors go out of scope)
     const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));
     if (sb.jagged) {
@@ -1431,17 +1536,22 @@ static int symm_setup(kmcf_tstate *t)
                                                              p->tol, p->m_e, p->V0, sb.d_tiles);
     }
     KMCF_HIP(hipGetLastError());
-    // diagonal = -(row sums): one application to the vector of ones (the diagonal entries are still 0)
+    // diagonal = -(row sums): one application to the vector of ones (the diagonal entries are still 0); spread: of ALL
+    // points on every rank (a rank sets the diagonal of the diagonal tiles it holds)
     fill_kernel<<<grid1d(64 * nb), KMCF_BLOCK, 0, st>>>(64 * nb, sb.d_xsub, 1.0);
     KMCF_HIP(hipMemsetAsync(t->d_tdiag, 0, (size_t)n_t * sizeof(double), st));
     KMCF_TRY(symm_launch<0>(sb, sb.d_xsub, 0.0, st));
-    sub_symm_reduce_kernel<0, false><<<nb, KMCF_BLOCK, 0, st>>>(n_t, nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart, nullptr, nullptr,
-                                                                        t->d_tdiag, nullptr, nullptr, nullptr, 0);
+    if (sb.spread)
+        KMCF_TRY((symm_spread_finish<0, false>(c, sb, n_t, 0, nullptr, nullptr, t->d_tdiag, nullptr, nullptr, nullptr, 0)));
+    else
+        sub_symm_reduce_kernel<0, false><<<nb, KMCF_BLOCK, 0, st>>>(n_t, nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart, nullptr, nullptr,
+                                                                            t->d_tdiag, nullptr, nullptr, nullptr, 0);
     if (sb.jagged) symj_set_diag_kernel<<<std::max(1, (nb + 3) / 4), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_jmask, sb.d_jvoff, sb.d_jval);
-    else symm_set_diag_kernel<<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_tiles);
+    else symm_set_diag_kernel<<<grid1d(n_t), KMCF_BLOCK, 0, st>>>(n_t, nb, t->d_tdiag, t->d_tdiag, sb.d_tiles, sb.spread ? sb.d_tile_local : nullptr);
     KMCF_HIP(hipMemsetAsync(sb.d_xsub, 0, (size_t)64 * nb * sizeof(double), st));      // the pad behind the last point stays 0
     KMCF_HIP(hipGetLastError());
-    sb.grid = nb;                                                   // blocks = partials of the reduce kernel
+    // partials of the p.Ap sum: one per block row (reduce kernel) / per 256 own points (combine kernel)
+    sb.grid = sb.spread ? (sb.n_loc + KMCF_BLOCK - 1) / KMCF_BLOCK : nb;
     return KMCF_OK;
 }
 
@@ -1510,10 +1620,11 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
     KMCF_TRY(ensure(&sb.d_mask, &sb.cap_mask, (size_t)ns * ng + 1));
     KMCF_TRY(ensure(&sb.d_xsub, &sb.cap_x, (size_t)n_t + 320));          // + 256: the 4-group unroll reads x_sub[j + 192] only when set
     KMCF_TRY(ensure(&t->d_rowcnt, &t->cap_rowcnt, (size_t)ns + 1));
-    KMCF_TRY(ensure(&t->d_tdiag, &t->cap_tdiag, (size_t)ns + 1));
+    KMCF_TRY(ensure(&t->d_tdiag, &t->cap_tdiag, (size_t)n_t + 1));       // (per LOCAL point; the spread tiles: per point of all ranks)
     const int wpb = KMCF_BLOCK / 64;
     const int wgrid = std::max(1, std::min((ns + wpb - 1) / wpb, KMCF_MAX_PARTIALS));
     sb.grid = ns > 0 ? wgrid : 0;
+    sb.dense = sb.jagged = sb.spread = false;
     if (ns > 0) {
         sub_rows_kernel<<<grid1d(ns), KMCF_BLOCK, 0, st>>>(ns, sb.row0, t->d_tidx, m->row0, t->d_inv_perm, sb.d_rows);
         tunnel_mask_kernel<<<wgrid, KMCF_BLOCK, 0, st>>>(ns, sb.row0, n_t, ng, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist,
@@ -1524,43 +1635,67 @@ static int t_assemble_async(kmcf_tstate *t, const int *d_site_element, const int
         KMCF_HIP(hipMemcpyAsync(pin_nnz, sb.d_voff + ns, sizeof(long long), hipMemcpyDeviceToHost, st));
         KMCF_HIP(hipStreamSynchronize(st));
         sb.nnz = *pin_nnz;
-        // storage of the block: dense symmetric tiles for one rank when the block is more than a QUARTER full, else the
-        // bitmap + packed values.  In bytes the tiles (4 n^2) win from half full on (8 d n^2 + n^2 / 8 for the bitmap
-        // form); in time from a quarter on: the tile kernel streams at 5.3 TB/s, the bitmap kernel -- a load of 64 x d
-        // values per mask word -- at 2.7 (the reference's contact window at 40 nm, 44 % full: 3.8 against 6.3 ms per
-        // application).  Not when the tiles would take more than 60 % of the free device memory.  KMCF_SUB_DENSE=0 / 1 overrides.
-        // Round 4: the same tiles holding only their ENTRIES (jagged: 4 B per entry of the full block + 1 bit per position,
-        // the same sums bit for bit, 2.2 x less memory at 44 % -- but bound by its instruction count, not its bytes: the
-        // reference's window on the 4 x 4-cell device, 17 722 points, 44 % full: dense tiles 0.28, jagged tiles 0.41,
-        // bitmap 0.49 ms per iteration) where the dense tiles do not fit the device's memory.
-        // KMCF_SUB_DENSE = 0 bitmap / 1 dense tiles / 2 jagged tiles overrides.
+    }
+    // Storage of the block: dense symmetric tiles when the block is more than a QUARTER full, else the bitmap + packed
+    // values.  In bytes the tiles (4 n^2) win from half full on (8 d n^2 + n^2 / 8 for the bitmap form); in time from a
+    // quarter on: the tile kernel streams at 5.3 TB/s, the bitmap kernel -- a load of 64 x d values per mask word -- at 2.7
+    // (the reference's contact window at 40 nm, 44 % full: 3.8 against 6.3 ms per application).  Not when the tiles would
+    // take more than 60 % of the free device memory.
+    // Round 4: the same tiles holding only their ENTRIES (jagged: 4 B per entry of the full block + 1 bit per position,
+    // the same sums bit for bit, 2.2 x less memory at 44 % -- but bound by its instruction count, not its bytes: the
+    // reference's window on the 4 x 4-cell device, 17 722 points, 44 % full: dense tiles 0.28, jagged tiles 0.41,
+    // bitmap 0.49 ms per iteration) where the dense tiles do not fit the device's memory (one rank).
+    // A rank GROUP (round 4): the dense tiles' strips dealt to the ranks (kmcf_subop::spread) under the same rule,
+    // weighed on the whole block -- the ranks agree through one small all-gather (entries of their rows, and whether
+    // their share of the tiles fits) so that all of them take the same branch.
+    // KMCF_SUB_DENSE = 0 bitmap / 1 dense tiles / 2 jagged tiles (one rank; a group: dense tiles) overrides.
+    if (n_t > 0) {
+        const long long nbl = (n_t + 63) / 64, all_tiles = nbl * (nbl + 1) / 2;
         const double nn2 = (double)n_t * (double)n_t, nbt = nn2 / 8192;
-        sb.dense = P == 1 && n_t >= 2048 && 4.0 * (double)sb.nnz > nn2;
-        sb.jagged = false;
-        if (sb.dense && sb.cap_tiles < (size_t)((long long)((n_t + 63) / 64) * ((n_t + 63) / 64 + 1) / 2) * 4096) {
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && 4.0 * nn2 + 1024.0 * nbt > 0.6 * (double)fr) {
-                sb.jagged = 4.0 * (double)sb.nnz + 1544.0 * nbt <= 0.6 * (double)fr + 8.0 * (double)sb.cap_jval;
-                sb.dense = sb.jagged;
+        const char *env = getenv("KMCF_SUB_DENSE");
+        if (P == 1) {
+            sb.dense = n_t >= 2048 && 4.0 * (double)sb.nnz > nn2;
+            if (sb.dense && sb.cap_tiles < (size_t)all_tiles * 4096) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && 4.0 * nn2 + 1024.0 * nbt > 0.6 * (double)fr) {
+                    sb.jagged = 4.0 * (double)sb.nnz + 1544.0 * nbt <= 0.6 * (double)fr + 8.0 * (double)sb.cap_jval;
+                    sb.dense = sb.jagged;
+                }
             }
+            if (env) { sb.dense = atoi(env) != 0; sb.jagged = sb.dense && atoi(env) == 2; }
+            if (nbl > KMCF_MAX_PARTIALS) sb.dense = sb.jagged = false;       // (one p.Ap partial per block row)
+        } else if (!(env && atoi(env) == 0)) {
+            // what this rank would hold: every P-th strip; 32 KB a tile + its parts
+            const double share = ((double)all_tiles / P + nbl) * (32768.0 + 1024.0);
+            size_t fr = 0, tot = 0;
+            const bool fits = sb.cap_tiles * sizeof(double) >= share || (hipMemGetInfo(&fr, &tot) == hipSuccess && share <= 0.6 * (double)fr);
+            double *h_ag = reinterpret_cast<double *>(t->h_agree);
+            h_ag[0] = (double)sb.nnz; h_ag[1] = fits ? 1.0 : 0.0;
+            KMCF_HIP(hipMemcpyAsync(t->d_agree + 2 * rank, h_ag, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+            std::vector<int> cnt((size_t)P, 2), dsp((size_t)P);
+            for (int q = 0; q < P; ++q) dsp[q] = 2 * q;
+            KMCF_TRY(kmcf_comm_allgatherv_double(c, t->d_agree, cnt.data(), dsp.data()));
+            KMCF_HIP(hipMemcpyAsync(h_ag + 2, t->d_agree, (size_t)2 * P * sizeof(double), hipMemcpyDeviceToHost, st));
+            KMCF_HIP(hipStreamSynchronize(st));
+            double nnz_all = 0.0;
+            bool fit_all = true;
+            for (int q = 0; q < P; ++q) { nnz_all += h_ag[2 + 2 * q]; fit_all = fit_all && h_ag[3 + 2 * q] != 0.0; }
+            sb.dense = sb.spread = fit_all && (ns + KMCF_BLOCK - 1) / KMCF_BLOCK <= KMCF_MAX_PARTIALS &&
+                                   (env ? atoi(env) != 0 : n_t >= 2048 && 4.0 * nnz_all > nn2);
         }
-        if (const char *e = getenv("KMCF_SUB_DENSE")) { sb.dense = P == 1 && atoi(e) != 0; sb.jagged = sb.dense && atoi(e) == 2; }
-        if ((n_t + 63) / 64 > KMCF_MAX_PARTIALS) sb.dense = sb.jagged = false;       // (one p.Ap partial per block row)
         if (sb.dense) {
             KMCF_TRY(symm_setup(t));
-        } else {
+        } else if (ns > 0) {
             KMCF_TRY(ensure(&sb.d_val, &sb.cap_val, (size_t)sb.nnz + 64));
             tunnel_value_kernel<<<wgrid, KMCF_BLOCK, 0, st>>>(ns, sb.row0, ng, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist, p->tol,
                                                               p->m_e, p->V0, sb.d_mask, sb.d_voff, sb.d_val, t->d_tdiag);
             KMCF_HIP(hipGetLastError());
         }
-    } else {
-        sb.dense = sb.jagged = false;
     }
     // 4. preconditioner and right-hand side
     if (n_loc > 0) {
         copy_diag_rhs_kernel<<<grid1d(n_loc), KMCF_BLOCK, 0, st>>>(n_loc, t->d_diag, t->d_diag_tot, t->d_col_node, p->loop_G * p->Vd, t->d_rhs);
-        if (ns > 0) add_tunnel_diag_kernel<<<grid1d(ns), KMCF_BLOCK, 0, st>>>(ns, sb.d_rows, t->d_tdiag, t->d_diag_tot);
+        if (ns > 0) add_tunnel_diag_kernel<<<grid1d(ns), KMCF_BLOCK, 0, st>>>(ns, sb.d_rows, t->d_tdiag + (sb.spread ? sb.row0 : 0), t->d_diag_tot);
         invert_kernel<<<grid1d(n_loc), KMCF_BLOCK, 0, st>>>(n_loc, t->d_diag_tot, m->d_dinv);
         KMCF_HIP(hipGetLastError());
     }
@@ -1612,8 +1747,13 @@ int kmcf_subop_finish(kmcf_matrix *m, bool with_dot, bool skip_if_done)
         KMCF_HIP(hipStreamWaitEvent(st, c->ev_sub, 0));
         sb->gather_pending = false;
     }
-    if (sb->n_loc == 0) return KMCF_OK;
     double *part = m->d_part_a + 3 * KMCF_MAX_PARTIALS;
+    if (sb->spread) {                                                          // (every rank: also one without points of its own)
+        KMCF_TRY(symm_launch<0>(*sb, sb->d_xsub, 0.0, st, m->d_S, chk));
+        if (with_dot) return symm_spread_finish<0, true>(c, *sb, sb->n_loc, sb->row0, sb->d_rows, m->d_p, m->d_Ap, nullptr, part, m->d_S, chk);
+        return symm_spread_finish<0, false>(c, *sb, sb->n_loc, sb->row0, sb->d_rows, m->d_p, m->d_Ap, nullptr, part, m->d_S, chk);
+    }
+    if (sb->n_loc == 0) return KMCF_OK;
     if (sb->dense) {
         KMCF_TRY(symm_launch<0>(*sb, sb->d_xsub, 0.0, st, m->d_S, chk));       // (behind the stop: neither pass runs)
         if (with_dot)
@@ -1681,7 +1821,7 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
     const kmcf_subop &sb = t->sub;
     if (h_tunnel_idx && sb.n_glob) memcpy(h_tunnel_idx, t->h_tidx.data(), (size_t)sb.n_glob * sizeof(int));
     const int ns = sb.n_loc, ng = sb.n_groups;
-    if (h_diag && ns) KMCF_HIP(hipMemcpy(h_diag, t->d_tdiag, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_diag && ns) KMCF_HIP(hipMemcpy(h_diag, t->d_tdiag + (sb.spread ? sb.row0 : 0), (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> tiles;
     if (h_val && sb.nnz && sb.jagged) {                      // the same out of the layers of the jagged tiles
         tiles.assign((size_t)sb.n_tiles * 4096, 0.0);
@@ -1705,13 +1845,32 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
                     }
             }
         }
+    } else if (h_val && sb.nnz && sb.spread) {
+        // the tiles of this rank's rows lie on all ranks: the rows' entries are computed afresh as the bitmap storage
+        // would (the same values: one symmetric expression per pair), the diagonal entries are the ones in use
+        double *d_v = nullptr, *d_dg = nullptr;
+        KMCF_HIP(hipMalloc(reinterpret_cast<void **>(&d_v), ((size_t)sb.nnz + 64) * sizeof(double)));
+        if (hipMalloc(reinterpret_cast<void **>(&d_dg), ((size_t)ns + 1) * sizeof(double)) != hipSuccess) { hipFree(d_v); KMCF_HIP(hipErrorOutOfMemory); }
+        const int wgrid = std::max(1, std::min((ns + 3) / 4, KMCF_MAX_PARTIALS));
+        tunnel_value_kernel<<<wgrid, KMCF_BLOCK, 0, t->comm->stream>>>(ns, sb.row0, ng, t->d_tinfo, t->d_tx, t->d_ty, t->d_tz, t->d_tcb, t->nn_dist,
+                                                                      t->par.tol, t->par.m_e, t->par.V0, sb.d_mask, sb.d_voff, d_v, d_dg);
+        hipError_t e1 = hipGetLastError();
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(t->comm->stream);
+        if (e1 == hipSuccess) e1 = hipMemcpy(h_val, d_v, (size_t)sb.nnz * sizeof(double), hipMemcpyDeviceToHost);
+        hipFree(d_v); hipFree(d_dg);
+        KMCF_HIP(e1);
     } else if (h_val && sb.nnz && sb.dense) {                // values out of the upper tiles (test-sized blocks)
         tiles.resize((size_t)sb.n_tiles * 4096);
         KMCF_HIP(hipMemcpy(tiles.data(), sb.d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost));
     } else if (h_val && sb.nnz) {
         KMCF_HIP(hipMemcpy(h_val, sb.d_val, (size_t)sb.nnz * sizeof(double), hipMemcpyDeviceToHost));   // packed = CSR order
     }
-    if (h_row_ptr || h_col || !tiles.empty()) {
+    if (h_row_ptr || h_col || !tiles.empty() || (sb.spread && h_val)) {
+        std::vector<double> tdiag_now;
+        if (sb.spread && h_val && ns) {
+            tdiag_now.resize((size_t)ns);
+            KMCF_HIP(hipMemcpy(tdiag_now.data(), t->d_tdiag + sb.row0, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
+        }
         std::vector<unsigned long long> mk((size_t)ns * ng + 1);
         if (ns) KMCF_HIP(hipMemcpy(mk.data(), sb.d_mask, (size_t)ns * ng * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         int64_t pos = 0;
@@ -1722,6 +1881,7 @@ extern "C" int kmcf_tstate_get_tunnel(const kmcf_tstate *t, int *h_tunnel_idx, i
                 while (w) {
                     const int b = __builtin_ctzll(w);
                     if (h_col) h_col[pos] = g * 64 + b;
+                    if (sb.spread && h_val && g * 64 + b == sb.row0 + s) h_val[pos] = tdiag_now[(size_t)s];
                     if (!tiles.empty()) {
                         const int i = sb.row0 + s, j = g * 64 + b, lo = std::min(i, j), hi = std::max(i, j);
                         h_val[pos] = tiles[(size_t)symm_tile_index(sb.nb, lo >> 6, hi >> 6) * 4096 + (size_t)(lo & 63) * 64 + (hi & 63)];
@@ -1781,14 +1941,24 @@ extern "C" int kmcf_update_power_sparse(kmcf_tstate *t, const int *d_site_elemen
         if (n_loc > 0) {
             power_neighbour_kernel<16><<<grid1d((int64_t)n_loc * 16), KMCF_BLOCK, 0, st>>>(
                 n_loc, m->d_row_ptr, m->d_col, m->d_val, t->d_diag_pos, t->d_col_node, d_atom_virtual_potentials, p->Vd, psum, isum);
-            if (t->sub.n_loc > 0 && t->sub.dense) {
+            KMCF_HIP(hipGetLastError());
+        }
+        if (t->sub.spread) {                                               // (every rank of the group: its strips, then the gather)
+            kmcf_subop &sb = t->sub;
+            gather_tunnel_pot_kernel<<<grid1d(sb.n_glob), KMCF_BLOCK, 0, st>>>(sb.n_glob, t->d_tidx, d_atom_virtual_potentials, sb.d_xsub);
+            KMCF_TRY(symm_launch<1>(sb, sb.d_xsub, p->Vd, st));
+            KMCF_TRY((symm_spread_finish<1, false>(c, sb, sb.n_loc, sb.row0, sb.d_rows, nullptr, psum, isum, nullptr, nullptr, 0)));
+            KMCF_HIP(hipMemsetAsync(sb.d_xsub + sb.n_glob, 0, (size_t)(64 * sb.nb - sb.n_glob) * sizeof(double), st));
+        }
+        if (n_loc > 0) {
+            if (t->sub.n_loc > 0 && t->sub.dense && !t->sub.spread) {
                 kmcf_subop &sb = t->sub;
                 gather_tunnel_pot_kernel<<<grid1d(sb.n_glob), KMCF_BLOCK, 0, st>>>(sb.n_glob, t->d_tidx, d_atom_virtual_potentials, sb.d_xsub);
                 KMCF_TRY(symm_launch<1>(sb, sb.d_xsub, p->Vd, st));
                 sub_symm_reduce_kernel<1, false><<<sb.nb, KMCF_BLOCK, 0, st>>>(sb.n_glob, sb.nb, sb.d_strip_first, sb.d_rowpart, sb.d_colpart,
                                                                                           sb.d_rows, nullptr, psum, isum, nullptr, nullptr, 0);
                 KMCF_HIP(hipMemsetAsync(sb.d_xsub + sb.n_glob, 0, (size_t)(64 * sb.nb - sb.n_glob) * sizeof(double), st));
-            } else if (t->sub.n_loc > 0)
+            } else if (t->sub.n_loc > 0 && !t->sub.dense)
                 power_tunnel_kernel<<<t->sub.grid, KMCF_BLOCK, 0, st>>>(t->sub.n_loc, t->sub.row0, t->sub.n_groups, t->sub.d_mask, t->sub.d_voff,
                                                                        t->sub.d_val, t->d_tidx, t->sub.d_rows, d_atom_virtual_potentials, p->Vd,
                                                                        psum, isum);

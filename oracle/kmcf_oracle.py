@@ -293,7 +293,7 @@ class _DevPlan(C.Structure):
                 ("boundary_grid", C.c_int), ("boundary_lpr", C.c_int), ("n_boundary", C.c_int), ("boundary_rows", _ipt),
                 ("n_long_items", C.c_int), ("long_items", _ipt), ("sub_grid", C.c_int), ("sub_n", C.c_int), ("sub_rows", _ipt),
                 ("sub_rp", _ipt), ("sub_col", _ipt), ("sub_val", _dpt), ("sub_dense", C.c_int), ("sub_n_glob", C.c_int),
-                ("sub_strip", C.c_int), ("sub_full", _dpt)]
+                ("sub_strip", C.c_int), ("sub_full", _dpt), ("sub_row0", C.c_int), ("sub_total", _dpt)]
 
 
 class DeviceRank:
@@ -337,7 +337,11 @@ class DeviceRank:
         # dense symmetric storage of the block (one rank): the full block as a dense array for the tile walk
         self.sub_full = np.zeros(1)
         dense = int(bool(sub is not None and sub.get("dense")))
-        if dense:
+        self.spread = bool(dense and sub.get("spread"))        # the tiles' strips dealt to the ranks of a group (pcg_device_order_ranks)
+        self.sub_strip = int(sub.get("strip", 16)) if dense else 16
+        if self.spread:
+            dense = 2
+        elif dense:
             nt = len(self.sub_rows)
             full = np.zeros((nt, nt))
             rows_of = np.repeat(np.arange(nt), np.diff(self.sub_rp))
@@ -347,7 +351,7 @@ class DeviceRank:
                           int(plan["sell_grid"]), len(self.tile_first), pi(self.tile_first), pi(self.tile_rows),
                           int(plan["boundary_grid"]), int(plan["boundary_lpr"]), len(self.boundary), pi(self.boundary),
                           len(items), pi(self.long_items), sub_grid, sub_n, pi(self.sub_rows), pi(self.sub_rp), pi(self.sub_col),
-                          pd(self.sub_val), dense, sub_n if dense else 0, int(sub.get("strip", 16)) if dense else 16, pd(self.sub_full))
+                          pd(self.sub_val), dense, sub_n if dense == 1 else 0, self.sub_strip, pd(self.sub_full), 0, pd(self.sub_full))
         assert len(self.boundary) == int(plan["boundary_rows"]) or self.n_halo == 0
         assert len(items) == int(plan["long_items"])
 
@@ -357,6 +361,7 @@ def _order_lib():
     if not hasattr(L, "_dev_ready"):
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
         L.orc_dev_spmv.argtypes = [C.POINTER(_DevPlan), _dp, _dp, _dp, C.c_int, dp]
+        L.orc_sub_tiles_part.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp]
         L.orc_dev_init.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, dp, dp]
         L.orc_dev_p.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double]
         L.orc_dev_x.argtypes = [C.c_int, _dp, _dp, C.c_double]
@@ -488,6 +493,25 @@ def pcg_device_order_ranks(ranks, counts, displs, rhs, x0, dinv, tol, max_it, fi
             acc += v
         return acc
 
+    # tunnel block as dense symmetric tiles whose strips are dealt to the ranks (kmcf_subop::spread): the whole block
+    # from the ranks' row slices, once
+    spread = any(rk.spread for rk in ranks)
+    if spread:
+        assert all(rk.spread or not rk.c.sub_n for rk in ranks)
+        F = np.zeros((n_sub, n_sub))
+        for q, rk in enumerate(ranks):
+            if rk.c.sub_n:
+                rows_of = np.repeat(np.arange(rk.c.sub_n), np.diff(rk.sub_rp)) + int(sub_displs[q])
+                F[rows_of, rk.sub_col] = rk.sub_val
+        F = np.ascontiguousarray(F)
+        SL = max(rk.sub_strip for rk in ranks)
+        sub_total = np.zeros(64 * ((n_sub + 63) // 64))
+        ypart = np.zeros_like(sub_total)
+        dpt = C.POINTER(C.c_double)
+        for q, rk in enumerate(ranks):
+            rk.c.sub_row0 = int(sub_displs[q])
+            rk.c.sub_total = sub_total.ctypes.data_as(dpt)
+
     def spmv(key, with_dot):
         """Ap = A v on every rank for v = st[key] (own rows); returns the local p.Ap sums"""
         glob = np.zeros(n_glob)
@@ -498,6 +522,11 @@ def pcg_device_order_ranks(ranks, counts, displs, rhs, x0, dinv, tol, max_it, fi
             for q, rk in enumerate(ranks):
                 if rk.c.sub_n:
                     xsub[int(sub_displs[q]):int(sub_displs[q]) + rk.c.sub_n] = st[q][key][rk.sub_rows]
+        if spread:                                 # every rank's partial of all sums, added in rank order (sub_combine_kernel)
+            sub_total[:] = 0.0
+            for q in range(P):
+                L.orc_sub_tiles_part(n_sub, SL, F, xsub, q, P, ypart)
+                sub_total[:] = sub_total + ypart
         out = []
         for q, rk in enumerate(ranks):
             xv = st[q]["xv"]

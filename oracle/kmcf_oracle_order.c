@@ -575,7 +575,68 @@ typedef struct {
     int sub_dense;                                /* 1: the block is applied from dense symmetric 64 x 64 tiles       */
     int sub_n_glob, sub_strip;                    /* points of all ranks (= this rank's: one rank only); tiles per strip */
     const double *sub_full;                       /* sub_n_glob x sub_n_glob, row-major, zeros where there is no entry */
+    int sub_row0;                                 /* sub_dense == 2 (tiles spread over a rank group): first point of this rank */
+    const double *sub_total;                      /* ... and the sums of ALL points, the ranks' partials added in rank order
+                                                   * (orc_sub_tiles_part per rank, then the caller)                    */
 } orc_dev_plan;
+
+/* One rank's partial sums of the tile walk when the strips of the upper block triangle are dealt to P ranks (each strip
+ * of the global list -- block rows ascending, J0 = I, I + SL, ... -- to the rank holding the fewest tiles so far, the
+ * lowest such rank; csrc/kmcf_tstate.hip: symm_setup, sub_symm_reduce_kernel with tile_local / ypart): for block row B,
+ * wave w adds the column parts of THIS rank's tiles (K, B) among K = w, w + 4, ... < B and the row parts of this rank's
+ * strips of block row B, the k-th of them by wave k mod 4; joined as ((c0 + c1) + (c2 + c3)) + ((r0 + r1) + (r2 + r3))
+ * into ypart[64 B + l] (all 64 nb of them). */
+void orc_sub_tiles_part(int nt, int SL, const double *F, const double *xsub, int q, int P, double *ypart)
+{
+    const int nb = (nt + 63) / 64;
+    int *gfirst = (int *)calloc((size_t)nb + 1, sizeof(int));       /* global index of the first strip of every block row */
+    for (int I = 0; I < nb; ++I) gfirst[I + 1] = gfirst[I] + (nb - I + SL - 1) / SL;
+    int *owner = (int *)calloc((size_t)gfirst[nb] + 1, sizeof(int));
+    {
+        long long *held = (long long *)calloc((size_t)P, sizeof(long long));
+        int s = 0;
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; J += SL, ++s) {
+                int o = 0;
+                for (int r = 1; r < P; ++r)
+                    if (held[r] < held[o]) o = r;
+                owner[s] = o;
+                held[o] += J + SL < nb ? SL : nb - J;
+            }
+        free(held);
+    }
+#define FV(i, j) (((i) < nt && (j) < nt) ? F[(size_t)(i) * nt + (j)] : 0.0)
+#define XS(j) ((j) < nt ? xsub[j] : 0.0)
+    for (int B = 0; B < nb; ++B) {
+        double cw[4][64], rw[4][64];
+        memset(cw, 0, sizeof(cw)); memset(rw, 0, sizeof(rw));
+        for (int wv = 0; wv < 4; ++wv)
+            for (int K = wv; K < B; K += 4) {
+                if (owner[gfirst[K] + (B - K) / SL] != q) continue; /* tile (K, B) lies in another rank's strip */
+                for (int c = 0; c < 64; ++c) {
+                    double ca = 0.0;
+                    for (int r = 0; r < 64; ++r) ca += FV(64 * K + r, 64 * B + c) * XS(64 * K + r);
+                    cw[wv][c] += ca;
+                }
+            }
+        int k = 0, sidx = 0;
+        for (int J0 = B; J0 < nb; J0 += SL, ++sidx) {
+            if (owner[gfirst[B] + sidx] != q) continue;
+            const int wv = k++ & 3, J1 = J0 + SL < nb ? J0 + SL : nb;
+            for (int r = 0; r < 64; ++r) {
+                double ra = 0.0;
+                for (int J = J0; J < J1; ++J)
+                    for (int c = 0; c < 64; ++c) ra += FV(64 * B + r, 64 * J + c) * XS(64 * J + c);
+                rw[wv][r] += ra;
+            }
+        }
+        for (int l = 0; l < 64; ++l)
+            ypart[64 * B + l] = ((cw[0][l] + cw[1][l]) + (cw[2][l] + cw[3][l])) + ((rw[0][l] + rw[1][l]) + (rw[2][l] + rw[3][l]));
+    }
+#undef FV
+#undef XS
+    free(gfirst); free(owner);
+}
 
 /* One distributed SpMV of one rank, y = A x with x = [own | halo] (+ S x_sub on the sub rows), every row and every
  * p.Ap partial in the order of the kernel that computes it on the device (kmcf_spmv_device, csrc/kmcf_spmv.hip):
@@ -678,6 +739,22 @@ void orc_dev_spmv(const orc_dev_plan *pl, const double *x, const double *xsub, d
      * runs on through the strip's tiles; lane c adds column c's products row by row (not for diagonal tiles).  Block row
      * B: wave w adds the column parts of tiles (K, B), K = w, w + 4, ... < B and the strips first + w, + 4, ...; joined
      * as ((c0 + c1) + (c2 + c3)) + ((r0 + r1) + (r2 + r3)); one p.Ap partial per block row. */
+    if (pl->sub_grid > 0 && pl->sub_n > 0 && pl->sub_dense == 2) {
+        /* tiles spread over the rank group: sub_combine_kernel -- a lane per own point, one p.Ap partial per 256 of them */
+        for (int b = 0; b < pl->sub_grid; ++b) {
+            double dot[BLK];
+            for (int t = 0; t < BLK; ++t) {
+                const int sr = b * BLK + t;
+                dot[t] = 0.0;
+                if (sr >= pl->sub_n) continue;
+                const double a = pl->sub_total[pl->sub_row0 + sr];
+                const int r = pl->sub_rows[sr];
+                y[r] += a;
+                dot[t] = x[r] * a;
+            }
+            pd[b] = block_sum(dot);
+        }
+    } else
     if (pl->sub_grid > 0 && pl->sub_n > 0 && pl->sub_dense) {
         const int nt = pl->sub_n_glob, nb = (nt + 63) / 64, SL = pl->sub_strip;
         const double *F = pl->sub_full;

@@ -41,14 +41,15 @@ def _make(km, torch, xyz, element, charge, cb, metals, n1, layers, comm, nn_dist
     return buf
 
 
-def _device_rank(km, oracle, buf, row0, dense=False):
-    """What fixes one rank's summation order + the system as assembled on the device (for oracle.pcg_device_order_ranks)."""
+def _device_rank(km, oracle, buf, row0, dense=False, spread=False, strip=16):
+    """What fixes one rank's summation order + the system as assembled on the device (for oracle.pcg_device_order_ranks).
+    spread: the tunnel block's tiles are dealt to the ranks of the group (strip: tiles per strip, KMCF_SUB_STRIP)."""
     S = km.solvers
     mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_tstate_matrix(buf.T_distributed))
     plan, v, tn = mat.sum_plan(), S.t_vectors(buf), S.t_tunnel(buf)
     ns = len(tn["row_ptr"]) - 1
     sub = dict(grid=plan["sub_grid"], rows=tn["tunnel_idx"][tn["first"]:tn["first"] + ns] + 2 - row0, row_ptr=tn["row_ptr"],
-               col=tn["col"], val=tn["val"], dense=dense)
+               col=tn["col"], val=tn["val"], dense=dense or spread, spread=spread, strip=strip)
     return dict(rank=oracle.DeviceRank(plan, sub), rhs=v["rhs"], dinv=v["dinv"], ns=ns, variant="cg1r" if plan["cg_variant"] else "classic")
 
 
@@ -308,14 +309,20 @@ def test_inprocess_builds_read_what_was_uploaded(km, oracle, torch):
         assert not errs, "\n".join(errs)
 
 
+@pytest.mark.parametrize("storage", ["bitmap", "tiles"])
 @pytest.mark.parametrize("transport", ["loopback", "p2p"])
 @pytest.mark.parametrize("P", [2, 3])
-def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):
+def test_small_device_multirank(km, oracle, torch, P, transport, storage, monkeypatch):
     """Row-partitioned T over an in-process group: halo exchange of the neighbour part, all-gather of the tunnel
     sub-vector, replicated current and power.  transport "loopback": host-synchronous exchanges, in order; "p2p": the
     device-side peer-to-peer protocol, where the sub-vector all-gather runs on the comm stream underneath the
     neighbour part of every SpMV (kmcf_subop_begin / _finish).  Same results, bit for bit (the oracle's device-order run
-    does not know the transport)."""
+    does not know the transport).  storage "bitmap": every rank holds its rows of the tunnel block (bitmap + packed
+    values); "tiles": the block as dense symmetric 64 x 64 tiles whose strips are dealt to the ranks (what a group gets for
+    a block more than a quarter full; KMCF_SUB_DENSE=1 forces it at this size, strips of one tile so that every rank holds
+    one), the ranks' partial sums all-gathered and added in rank order -- against the oracle walking the same tiles."""
+    monkeypatch.setenv("KMCF_SUB_DENSE", "1" if storage == "tiles" else "0")
+    monkeypatch.setenv("KMCF_SUB_STRIP", "1")
     if transport == "p2p":
         monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
         monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
@@ -342,13 +349,15 @@ def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):
             S.t_assemble(buf, prm)
             r0, nr = int(comm.displs_T[r]), int(comm.counts_T[r])
             _compare_assembly(S, buf, T, r0, nr)
+            assert S.t_info(buf)["tunnel_dense"] == (1 if storage == "tiles" else 0)
             buf.site_power.fill_(-7.0)
             im, st = S.update_power_gpu_sparse_dist(buf, d["n1"], d["n1"], d["layers"], PAR["Vd"], PAR["high_G"], PAR["low_G"],
                                                     PAR["loop_G"], G0, PAR["tol"], PAR["nn_dist"], PAR["m_e"], PAR["V0"], 2, True,
                                                     False, 1.0, cg_tolerance=1e-13, cg_max_iterations=20000, contact_x_lo=x_lo,
                                                     contact_x_hi=x_hi)
             out[r] = dict(im=im, st=st, v=buf.atom_virtual_potentials.cpu().numpy().copy(),
-                          pw=buf.site_power.cpu().numpy().copy(), part=_device_rank(km, oracle, buf, r0), r0=r0, nr=nr)
+                          pw=buf.site_power.cpu().numpy().copy(), part=_device_rank(km, oracle, buf, r0, spread=storage == "tiles", strip=1),
+                          r0=r0, nr=nr, info=S.t_info(buf))
             buf.freeGPUmemory()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -363,6 +372,10 @@ def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):
     assert all(o is not None for o in out), "a rank did not finish"
     for c in comms:
         c.close()
+    if storage == "tiles":                             # every rank holds a share of the tiles
+        nb = (out[0]["info"]["tunnel_points"] + 63) // 64
+        held = [o["info"]["tunnel_bytes"] // 32768 for o in out]
+        assert sum(held) == nb * (nb + 1) // 2 and min(held) > 0, (held, nb)
     xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-13, 20000)
     m = np.zeros(T.N_atom + 2)
     m[:T.Nsub] = xo * G0
@@ -384,6 +397,87 @@ def test_small_device_multirank(km, oracle, torch, P, transport, monkeypatch):
         np.testing.assert_array_equal(o["pw"] == -7.0, pw == -7.0)
         tight = np.r_[0, 1, 2 + np.nonzero(np.isin(T.atom_element[:-1], [TI, N_EL]))[0]]
         assert np.abs(o["v"][tight] - m[tight]).max() <= 2e-6 * np.abs(m).max()
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_5nm_device_rank_group_holds_the_tunnel_block_as_tiles(km, oracle, dev5, ref5, torch, monkeypatch, P):
+    """The reference's 5 nm device over a group of P ranks on the peer-to-peer transport with the tunnel block (1913 points,
+    30 block rows) as dense symmetric tiles whose 44 strips are dealt to the ranks (kmcf_subop::spread; KMCF_SUB_DENSE=1
+    forces it below 2048 points): every rank forms its partial of all sums from the strips it holds, the partials are
+    all-gathered and added in rank order.  Held against the oracle walking the same tiles rank by rank -- iteration
+    count and every potential identical -- and against the group holding the block as row slices (bitmap): the same
+    current to the solver's tolerance, the same power pattern."""
+    S = km.solvers
+    d = dev5
+    monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+    monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
+    par = dict(Vd=d["Vd"], high_G=1e5 * d["high_G"], low_G=d["low_G"], loop_G=1e7 * d["high_G"], tol=Q * 0.01, m_e=0.85 * 9.11e-31, V0=1.6)
+    NL, xyz, element = d["N_contact"], d["xyz"], d["element"]
+    cb = 1.60217663e-19 * d["Vd"] * (0.5 - np.clip(xyz[:, 0] / 52.0, 0, 1))
+    N = len(element)
+    na = int(np.isin(element, [0, 1], invert=True).sum())
+    res = {}
+    for storage in ("tiles", "bitmap"):
+        monkeypatch.setenv("KMCF_SUB_DENSE", "1" if storage == "tiles" else "0")
+        comms = S.KMC_comm.loopback_group(na + 1, na + 1, N, N, P)
+        out, errs = [None] * P, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(0)
+                comm = comms[r]
+                buf = S.GPUBuffers(N, element, xyz[:, 0], xyz[:, 1], xyz[:, 2], 52, d["sigma"], d["k"], d["lattice"], d["metals"])
+                buf.site_charge.copy_(torch.as_tensor(np.asarray(ref5["charge"], np.int32)))
+                buf.site_CB_edge = torch.as_tensor(cb, device="cuda")
+                S.initialize_sparsity_T(buf, 0, d["nn_dist"], NL, NL, 10, comm)
+                prm = S.current_params(par["Vd"], par["high_G"], par["low_G"], par["loop_G"], G0, par["tol"], par["m_e"], par["V0"])
+                S.t_assemble(buf, prm)
+                info = S.t_info(buf)
+                buf.atom_virtual_potentials.zero_()
+                buf.site_power.zero_()
+                im, st = S.update_power_gpu_sparse_dist(buf, NL, NL, 10, par["Vd"], par["high_G"], par["low_G"], par["loop_G"], G0, par["tol"],
+                                                        d["nn_dist"], par["m_e"], par["V0"], len(d["metals"]), True, False, 1.0,
+                                                        cg_tolerance=1e-13, cg_max_iterations=20000)
+                r0, nr = int(comm.displs_T[r]), int(comm.counts_T[r])
+                out[r] = dict(im=im, st=st, info=info, v=buf.atom_virtual_potentials.cpu().numpy().copy(), pw=buf.site_power.cpu().numpy().copy(),
+                              part=_device_rank(km, oracle, buf, r0, spread=storage == "tiles") if storage == "tiles" else None, r0=r0, nr=nr)
+                buf.freeGPUmemory()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(240)
+        assert not errs, "\n".join(errs)
+        assert all(o is not None for o in out), "a rank did not finish"
+        for c in comms:
+            c.close()
+        for o in out:
+            assert o["st"]["converged"] == 1 and o["info"]["tunnel_points"] == 1913
+            assert o["info"]["tunnel_dense"] == (1 if storage == "tiles" else 0)
+            np.testing.assert_array_equal(o["v"], out[0]["v"])
+            np.testing.assert_array_equal(o["pw"], out[0]["pw"])
+            assert o["im"] == out[0]["im"]
+        res[storage] = out
+    tl, bm = res["tiles"], res["bitmap"]
+    held = [o["info"]["tunnel_bytes"] // 32768 for o in tl]
+    assert sum(held) == 30 * 31 // 2 and max(held) - min(held) <= 16, held             # 465 tiles, a strip's length apart at most
+    n = na + 1
+    od = _device_order_solve(oracle, [o["part"] for o in tl], [o["nr"] for o in tl], [o["r0"] for o in tl], 1e-13, 20000)
+    mo = od["x"] * G0
+    mo = mo + abs(min(mo[2:].min(), 0.0))
+    assert tl[0]["st"]["iterations"] == od["iterations"], (tl[0]["st"]["iterations"], od["iterations"])
+    np.testing.assert_array_equal(tl[0]["v"][:n], mo)
+    print("T 5 nm over %d ranks, tunnel block as tiles (%s per rank): %d iterations (oracle in the device's order: %d; row slices: %d), "
+          "I_macro %.9e against %.9e" % (P, held, tl[0]["st"]["iterations"], od["iterations"], bm[0]["st"]["iterations"], tl[0]["im"], bm[0]["im"]))
+    assert abs(tl[0]["st"]["iterations"] - bm[0]["st"]["iterations"]) <= max(3, 0.1 * bm[0]["st"]["iterations"])
+    # (two summation orders under one stopping rule: the source node's residual is what separates the currents -- 2e-5 of it here)
+    assert abs(tl[0]["im"] - bm[0]["im"]) <= 1e-4 * abs(bm[0]["im"])
+    assert np.abs(tl[0]["pw"] - bm[0]["pw"]).max() <= 1e-3 * np.abs(bm[0]["pw"]).max() + 1e-300
+    np.testing.assert_array_equal(tl[0]["pw"] == 0, bm[0]["pw"] == 0)
 
 
 @pytest.mark.parametrize("device", ["small", "5nm"])

@@ -238,3 +238,46 @@ def test_resident_order_restatement_is_the_same_recurrence(oracle, ref5):
     assert cf["iterations"] == 7 and not cf["converged"]
     # the two trees are different computations: not bit-identical (or the test would prove nothing about the tree)
     assert not np.array_equal(out["tpb4"][1]["x"], out["loop"][1]["x"]) or not np.array_equal(out["tpb1"][1]["x"], out["loop"][1]["x"])
+
+
+def test_spread_tile_walk_is_the_same_operator(oracle):
+    """oracle/kmcf_oracle_order.c: orc_sub_tiles_part (the dense symmetric tiles of the tunnel block with their strips
+    dealt to P ranks, csrc/kmcf_tstate.hip kmcf_subop::spread): the ranks' partials add up to S x (to rounding, against
+    a plain product), every tile is walked by exactly one rank (a block of ones: the partials count entries), and for
+    P = 1 the walk IS the single-rank tile walk of orc_dev_spmv, bit for bit."""
+    import ctypes as C
+    import numpy as np
+    L = oracle._order_lib()
+    rng = np.random.default_rng(3)
+    nt = 333                                        # 6 block rows, the last one ragged
+    A = rng.standard_normal((nt, nt)) * (rng.random((nt, nt)) < 0.4)
+    F = np.ascontiguousarray(np.triu(A, 1) + np.triu(A, 1).T + np.diag(rng.standard_normal(nt)))
+    x = rng.standard_normal(nt)
+    npad = 64 * ((nt + 63) // 64)
+    for SL in (1, 2, 16):
+        parts = {}
+        for P in (1, 2, 3, 5):
+            tot, cnt = np.zeros(npad), np.zeros(npad)
+            for q in range(P):
+                yp, cp = np.zeros(npad), np.zeros(npad)
+                L.orc_sub_tiles_part(nt, SL, F, x, q, P, yp)
+                L.orc_sub_tiles_part(nt, SL, np.ones((nt, nt)), np.ones(nt), q, P, cp)
+                tot, cnt = tot + yp, cnt + cp
+            np.testing.assert_array_equal(cnt[:nt], np.full(nt, float(nt)))       # every entry once, over all ranks
+            assert np.all(tot[nt:] == 0) and np.abs(tot[:nt] - F @ x).max() <= 1e-12 * np.abs(F).sum(1).max() * np.abs(x).max()
+            parts[P] = tot
+        # P = 1 against the single-rank walk inside orc_dev_spmv (a zero neighbour matrix around it)
+        rp = np.arange(nt + 1, dtype=np.int32)      # (one zero entry per row: y = 0 x + S x)
+        plan = dict(rows=nt, n_short=nt, halo_cols=0, vec_grid=8, sell_active=1, sell_ident=1, sell_grid=8, sub_grid=(nt + 63) // 64, cg_variant=0,
+                    tile_first=np.arange(0, nt, 256, dtype=np.int32), tile_rows=np.minimum(256, nt - np.arange(0, nt, 256)).astype(np.int32),
+                    row_ptr=rp, col=np.arange(nt, dtype=np.int32), val=np.zeros(nt), perm=np.arange(nt, dtype=np.int32), boundary_grid=0, boundary_lpr=1,
+                    boundary_rows=0, long_items=0)
+        nzr, nzc = np.nonzero(F)
+        srp = np.zeros(nt + 1, np.int32)
+        np.add.at(srp, nzr + 1, 1)
+        sub = dict(grid=(nt + 63) // 64, rows=np.arange(nt, dtype=np.int32), row_ptr=np.cumsum(srp).astype(np.int32), col=nzc.astype(np.int32),
+                   val=F[nzr, nzc], dense=True, strip=SL)
+        rk = oracle.DeviceRank(plan, sub)
+        y, pap = np.zeros(nt + 1), C.c_double(0.0)
+        L.orc_dev_spmv(C.byref(rk.c), np.ascontiguousarray(x), np.ascontiguousarray(x), y, 0, C.byref(pap))
+        np.testing.assert_array_equal(y[:nt], parts[1][:nt])

@@ -25,13 +25,14 @@ pytestmark = pytest.mark.gpu
 Q = 1.60217663e-19
 
 
-def _device(km, filament):
+def _device(km, filament, comm=None, d=None):
     import torch
     S = km.solvers
-    d = km.structure.synth_crossbar_40nm(tiles=4, filament=filament)
+    d = d if d is not None else km.structure.synth_crossbar_40nm(tiles=4, filament=filament)
     N, NL = d["N"], d["N_contact"]
-    comm = S.KMC_comm(N - 2 * NL, N + 1, N, N)
-    comm.connect()
+    if comm is None:
+        comm = S.KMC_comm(N - 2 * NL, N + 1, N, N)
+        comm.connect()
     buf = S.GPUBuffers(N, d["element"], d["xyz"][:, 0], d["xyz"][:, 1], d["xyz"][:, 2], 52, d["sigma"], d["k"], d["lattice"], d["metals"])
     S.compute_neighbor_list(comm, buf, d["nn_dist"], 52)
     S.initialize_sparsity_K(buf, d["pbc"], d["nn_dist"], NL, comm)
@@ -39,17 +40,18 @@ def _device(km, filament):
                         comm.counts_events, comm.displs_events, comm)
     el = d["element"]
     N_atom = int(((el != 0) & (el != 1)).sum())
-    comm.counts_T, comm.displs_T = comm.partition(N_atom + 1, 1)
+    comm.counts_T, comm.displs_T = comm.partition(N_atom + 1, comm.size_T)
     return dict(S=S, d=d, comm=comm, buf=buf, N_atom=N_atom, torch=torch)
 
 
-def _current(dev, tol, dense=None, cb_scaled=None, first=False):
-    """CB edge -> T assembly (the reference's window) -> solve; returns (I_macro, loop-side current, stats, info, bound)."""
+def _current(dev, tol, dense=None, cb_scaled=None, first=False, touch_env=True, cb=None):
+    """CB edge -> T assembly (the reference's window) -> solve; returns (I_macro, loop-side current, stats, info, bound).
+    touch_env False: the environment is the caller's (a rank thread of a group must not change it under the others)."""
     S, d, buf, comm, N_atom = dev["S"], dev["d"], dev["buf"], dev["comm"], dev["N_atom"]
     N, NL = d["N"], d["N_contact"]
     high_G, low_G, loop_G = 1e5 * d["high_G"], d["low_G"], 1e7 * d["high_G"]
     G0 = 2 * 3.8612e-5 * 1e-5
-    env = {"KMCF_SUB_DENSE": dense, "KMCF_CB_SCALED": cb_scaled}
+    env = {"KMCF_SUB_DENSE": dense, "KMCF_CB_SCALED": cb_scaled} if touch_env else {}
     saved = {k: os.environ.get(k) for k in env}
     try:
         for k, v in env.items():
@@ -57,10 +59,13 @@ def _current(dev, tol, dense=None, cb_scaled=None, first=False):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        if buf.site_CB_edge is not None:
-            buf.site_CB_edge.zero_()
-        st_cb = S.update_CB_edge_gpu_sparse(buf, N, NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
-        assert st_cb["converged"] == 1
+        if cb is not None:                             # (a rank of a group: the band edge is a one-rank solve, as in the reference)
+            buf.site_CB_edge = dev["torch"].as_tensor(cb, device="cuda")
+        else:
+            if buf.site_CB_edge is not None:
+                buf.site_CB_edge.zero_()
+            st_cb = S.update_CB_edge_gpu_sparse(buf, N, NL, NL, d["Vd"], d["pbc"], d["high_G"], d["low_G"], d["nn_dist"], len(d["metals"]))
+            assert st_cb["converged"] == 1
         if first:
             S.initialize_sparsity_T(buf, d["pbc"], d["nn_dist"], NL, NL, 10, comm)
         prm = S.current_params(d["Vd"], high_G, low_G, loop_G, G0, Q * 0.01, 0.85 * 9.11e-31, 1.6)     # default window = the reference's
@@ -127,3 +132,73 @@ def test_conducting_crossbar_current_is_a_property_of_the_device(km):
     finally:
         dev0["buf"].freeGPUmemory()
         dev0["comm"].close()
+
+
+def test_conducting_crossbar_over_a_rank_group(km, monkeypatch):
+    """The same conducting device over a group of two ranks (in-process, peer-to-peer transport, ONE GPU: a correctness
+    test with a timing note, not a scaling measurement): the storage rule gives the group the tunnel block as dense
+    symmetric tiles with their strips dealt to the ranks (17 722 points, 44 % full; kmcf_subop::spread), no longer the
+    row-sliced bitmap form -- and the current is the one rank's, to the 1e-8 the other implementations of the operator
+    agree to.  (The band edge it is assembled from is solved on one rank, as in the reference, and handed to the group.)"""
+    import threading
+    import torch
+    S = km.solvers
+    monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
+    monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "60000")
+    monkeypatch.delenv("KMCF_CB_SCALED", raising=False)
+    d = km.structure.synth_crossbar_40nm(tiles=4, filament=4.0)
+    N, NL = d["N"], d["N_contact"]
+    N_atom = int(((d["element"] != 0) & (d["element"] != 1)).sum())
+    P = 2
+    # one rank first: its current (dense tiles; this file's first test: 3.861416942e-3) and the band edge for the group
+    monkeypatch.setenv("KMCF_SUB_DENSE", "1")
+    one = _device(km, 4.0, d=d)
+    try:
+        i1 = _current(one, 1e-18, first=True, touch_env=False)[0]
+        cb = one["buf"].site_CB_edge.cpu().numpy().copy()
+    finally:
+        one["buf"].freeGPUmemory()
+        one["comm"].close()
+    res = {}
+    for name, dense in (("tiles", None), ("bitmap", "0")):
+        if dense is None:
+            monkeypatch.delenv("KMCF_SUB_DENSE", raising=False)
+        else:
+            monkeypatch.setenv("KMCF_SUB_DENSE", dense)
+        comms = S.KMC_comm.loopback_group(N - 2 * NL, N_atom + 1, N, N, P)
+        out, errs = [None] * P, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(0)
+                dev = _device(km, 4.0, comm=comms[r], d=d)
+                try:
+                    out[r] = _current(dev, 1e-18, first=True, touch_env=False, cb=cb)
+                finally:
+                    dev["buf"].freeGPUmemory()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                errs.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(600)
+        assert not errs, "\n".join(errs)
+        assert all(o is not None for o in out), "a rank did not finish"
+        for c in comms:
+            c.close()
+        for im, il, st, info, bound in out:
+            assert st["converged"] == 1 and info["tunnel_points"] == 17722
+            assert info["tunnel_dense"] == (1 if name == "tiles" else 0)
+            assert im == out[0][0] and abs(im - il) <= max(bound * 1.01, 1e-25) and abs(im - il) <= 1e-8 * im
+        res[name] = out
+        print("  group of 2, %-6s: %d iterations, %.1f ms (%.3f ms per iteration; per rank %s GB), I_macro %.12e"
+              % (name, out[0][2]["iterations"], out[0][2]["ms_solve"], out[0][2]["ms_solve"] / out[0][2]["iterations"],
+                 " / ".join("%.2f" % (o[3]["tunnel_bytes"] * 1e-9) for o in out), out[0][0]))
+    nb = (17722 + 63) // 64
+    held = [o[3]["tunnel_bytes"] // 32768 for o in res["tiles"]]
+    assert sum(held) == nb * (nb + 1) // 2 and abs(held[0] - held[1]) <= 16
+    for name in res:
+        assert abs(res[name][0][0] - i1) <= 1e-8 * i1, (name, res[name][0][0], i1)

@@ -26,12 +26,12 @@ for c in range(cycles):
         torch.cuda.synchronize(); del junk; torch.cuda.empty_cache()
     for transport in ("loopback", "p2p"):
         for P in (2, 3):
+            storage = ("bitmap", "tiles")[c & 1]              # (the tunnel block as row slices / as tiles dealt to the ranks, alternately)
             try:
-                TT.test_small_device_multirank.__wrapped__(km, O, torch, P, transport, Env()) if hasattr(TT.test_small_device_multirank, "__wrapped__") \
-                    else TT.test_small_device_multirank(km, O, torch, P, transport, Env())
+                TT.test_small_device_multirank(km, O, torch, P, transport, storage, Env())
             except AssertionError as e:
                 bad += 1
-                print("cycle %d, P=%d, %s:\n%s" % (c, P, transport, str(e)[:3000]), flush=True)
+                print("cycle %d, P=%d, %s, %s:\n%s" % (c, P, transport, storage, str(e)[:3000]), flush=True)
                 if os.environ.get("KMCF_DEBUG_DUMP"):
                     print("stopping at the first failure (the dumps of its builds stay)"); sys.exit(0)
 print("%d failures in %d cycles" % (bad, cycles))

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         rb0 = __builtin_amdgcn_readfirstlane(df.x);
         rb1 = __builtin_amdgcn_readfirstlane(dl.x + dl.y);
     }
+    const int nwq = __builtin_amdgcn_readfirstlane((d.w + KMCF_BLOCK - 1) / KMCF_BLOCK);   // 256-slot stretches of the window that hold outside columns
+#pragma unroll
+    for (int q = 0; q < CGR_WQ; ++q)               // (the others are written once, here)
+#pragma unroll
+        for (int k = 0; k < ND; ++k) xs[k * CGR_W + KMCF_BLOCK + q * KMCF_BLOCK + t] = 0.0;
     bool sib[CGR_WQ];
 #pragma unroll
     for (int q = 0; q < CGR_WQ; ++q) sib[q] = TPB > 1 && A.sibling_lds && wc[q] >= rb0 && wc[q] < rb1;
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         for (int k = 0; k < ND; ++k) xs[k * CGR_W + t] = dv[k] * own;                 // (lanes without a row: own = 0)
 #pragma unroll
         for (int q = 0; q < CGR_WQ; ++q) {
+            if (q >= nwq) break;                           // (tile-uniform: the stretches past the tile's window keep their 0.0 -- the padding target, slot W - 1, among them)
 #pragma unroll
             for (int k = 0; k < ND; ++k) xs[k * CGR_W + KMCF_BLOCK + q * KMCF_BLOCK + t] = dv[k] * g[q];   // (past the window: 0.0, the padding target)
         }

@@ -311,6 +311,10 @@ int kmcf_enter(kmcf_comm *c)
     // against -- an event on the legacy null stream is not cheap
     if (!getenv("KMCF_ENTER_ALWAYS") && hipStreamQuery(c->caller_stream) == hipSuccess) return KMCF_OK;
     (void)hipGetLastError();                          // (hipErrorNotReady is the expected answer otherwise)
+    // (Seen on ROCm 7.2: after an upload of some MB from PAGEABLE host memory the null stream keeps answering "not
+    // ready" -- also after hipDeviceSynchronize, also when asked again -- until an event has been recorded on it: the
+    // next call pays this branch once, 40-100 us until its first kernel starts.  Uploads from pinned memory do not.)
+    if (getenv("KMCF_TRACE")) fprintf(stderr, "kmcf_enter: the caller's stream is busy (ordering behind an event on it)\n");
     KMCF_HIP(hipEventRecord(c->ev_entry, c->caller_stream));
     KMCF_HIP(hipStreamWaitEvent(c->stream, c->ev_entry, 0));
     return KMCF_OK;

@@ -100,6 +100,15 @@ __device__ __forceinline__ void ll_store_sys(u64 *p, double v, unsigned int seq)
     __hip_atomic_store(p, (b & 0xffffffffull) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(p + 1, (b >> 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// ... and as ONE 16-byte store (the granule is 16-byte aligned): half the packets over a link, and lanes that own
+// consecutive rows fill whole 64-byte requests.  Tear-safe like ll_store16: each 8-byte half carries the sequence number.
+typedef unsigned int cgr_u4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_store_sys16(u64 *p, double v, unsigned int seq)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const cgr_u4s d = {(unsigned int)b, seq, (unsigned int)(b >> 32), seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+}
 __device__ __forceinline__ bool ll_try_sys(const u64 *p, unsigned int seq, double &v)
 {
     const u64 a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         if (has_row) {
             if (zpar) ll_store16(zrs[1], 16u * (unsigned int)row, v, seq);
             else ll_store16(zrs[0], 16u * (unsigned int)row, v, seq);
-            for (int e = put0; e < put1; ++e) ll_store_sys(A.putr_ll[e] + zpar * A.putr_ll_stride[e], v, seq);
+            for (int e = put0; e < put1; ++e) ll_store_sys16(A.putr_ll[e] + zpar * A.putr_ll_stride[e], v, seq);
         }
     };
     // y_row = sum of the row's products with version `seq` of the vector whose own entry is `own`

@@ -365,6 +365,7 @@ struct kmcf_subop {
     double *d_ypart = nullptr;               // P x (1 or 2) x 64 nb: every rank's partial sums (rank q's at q W 64 nb)
     long long n_tiles_glob = 0;
     size_t cap_tile_local = 0, cap_ypart = 0;
+    std::vector<int> y_counts[2], y_displs[2];   // the all-gather of the partials: one sum per point (the operator) / two (the power pass)
     // ... or (jagged, with dense set: strips, parts and their reduction are shared) the same tiles holding only their
     // ENTRIES: tile-major row masks + the values in layers (kmcf_tstate.hip: sub_symj_kernel) -- 4 B per entry of the
     // full block + 1 bit per position instead of 4 B per position

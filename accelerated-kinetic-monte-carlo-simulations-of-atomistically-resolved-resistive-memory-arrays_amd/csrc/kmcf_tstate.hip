@@ -1454,9 +1454,7 @@ static int symm_spread_finish(kmcf_comm *c, kmcf_subop &sb, int ns, int row0, co
                                                                       nullptr, nullptr, nullptr, S, chk, sb.d_tile_local,
                                                                       sb.d_ypart + (size_t)c->rank * W * npad);
     KMCF_HIP(hipGetLastError());
-    std::vector<int> cnt((size_t)P, W * npad), dsp((size_t)P);
-    for (int q = 0; q < P; ++q) dsp[q] = q * W * npad;
-    KMCF_TRY(kmcf_comm_allgatherv_double(c, sb.d_ypart, cnt.data(), dsp.data()));
+    KMCF_TRY(kmcf_comm_allgatherv_double(c, sb.d_ypart, sb.y_counts[W - 1].data(), sb.y_displs[W - 1].data()));
     if (ns > 0) {
         sub_combine_kernel<MODE, DOT><<<(ns + KMCF_BLOCK - 1) / KMCF_BLOCK, KMCF_BLOCK, 0, st>>>(ns, row0, P, npad, sb.d_ypart, rows, p, y, y2, part, S, chk);
         KMCF_HIP(hipGetLastError());
@@ -1513,6 +1511,11 @@ static int symm_setup(kmcf_tstate *t)
         KMCF_TRY(ensure(&sb.d_tile_local, &sb.cap_tile_local, tile_local.size() + 1));
         KMCF_TRY(ensure(&sb.d_ypart, &sb.cap_ypart, (size_t)2 * P * 64 * nb));
         KMCF_HIP(hipMemcpyAsync(sb.d_tile_local, tile_local.data(), tile_local.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        for (int w = 1; w <= 2; ++w) {                              // slices of the partials' all-gather: one / two sums per point
+            sb.y_counts[w - 1].assign((size_t)P, w * 64 * nb);
+            sb.y_displs[w - 1].resize((size_t)P);
+            for (int q = 0; q < P; ++q) sb.y_displs[w - 1][q] = q * w * 64 * nb;
+        }
     }
     KMCF_HIP(hipStreamSynchronize(st));                            // (the host vectors go out of scope)
     const int grid = std::max(1, std::min((sb.n_strips + 3) / 4, 8192));

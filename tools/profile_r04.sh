@@ -50,7 +50,7 @@ cd /tmp
 KMCF_T_REPEAT=2 rocprofv3 --kernel-trace --stats -d $E/tpath -o t --output-format csv -- \
     python3 -m pytest $R/tests/test_gpu_fullsize.py::test_full_size_current_and_heat -x -q -s > $E/tpath.log 2>&1
 grep "T 40 nm\|CB edge" $E/tpath.log > $E/tpath_40nm.txt
-python3 -m pytest $R/tests/test_gpu_conducting.py -x -q -s 2>&1 | grep "conducting\|tol 1e-18\|filament\|passed\|failed" > $E/conducting_4x4.txt
+python3 -m pytest $R/tests/test_gpu_conducting.py -x -q -s 2>&1 | grep "conducting\|tol 1e-18\|filament\|group of\|passed\|failed" > $E/conducting_4x4.txt
 KMCF_T_FULL_WINDOW=1 python3 -m pytest $R/tests/test_gpu_fullsize.py::test_full_size_current_and_heat -x -q -s 2>&1 | grep "T 40 nm\|passed\|failed" > $E/tpath_40nm_reference_window.txt
 KMCF_SUB_DENSE=2 KMCF_T_FULL_WINDOW=1 python3 -m pytest $R/tests/test_gpu_fullsize.py::test_full_size_current_and_heat -x -q -s 2>&1 | grep "reference window\|passed\|failed" > $E/tpath_40nm_reference_window_jagged.txt
 # KMC loop

@@ -309,9 +309,8 @@ def test_inprocess_builds_read_what_was_uploaded(km, oracle, torch):
         assert not errs, "\n".join(errs)
 
 
-@pytest.mark.parametrize("storage", ["bitmap", "tiles"])
-@pytest.mark.parametrize("transport", ["loopback", "p2p"])
-@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("P,transport,storage", [(P, tr, stg) for P in (2, 3) for tr in ("loopback", "p2p") for stg in ("bitmap", "tiles")]
+                         + [(5, "p2p", "tiles")])      # (five ranks: the first and the last own contact atoms only -- no tunnel point of their own, tiles all the same)
 def test_small_device_multirank(km, oracle, torch, P, transport, storage, monkeypatch):
     """Row-partitioned T over an in-process group: halo exchange of the neighbour part, all-gather of the tunnel
     sub-vector, replicated current and power.  transport "loopback": host-synchronous exchanges, in order; "p2p": the
@@ -332,6 +331,8 @@ def test_small_device_multirank(km, oracle, torch, P, transport, storage, monkey
     d = small_device(seed=11)
     a = 2.5
     x_lo, x_hi = (d["layers"] - 1) * a - 0.1, (d["layers"] + 7) * a + 0.1
+    if P == 5:                                         # a window over the middle of the oxide only: the outer ranks own no tunnel point
+        x_lo, x_hi = (d["layers"] + 1) * a - 0.1, (d["layers"] + 5) * a + 0.1
     metals = np.array([TI, N_EL], np.int32)
     T = oracle.TSystem(d["xyz"], d["element"], d["charge"], d["cb"], metals, PAR["nn_dist"], d["n1"], d["n1"], d["layers"],
                        PAR["Vd"], PAR["high_G"], PAR["low_G"], PAR["loop_G"], PAR["tol"], PAR["m_e"], PAR["V0"], x_lo, x_hi)
@@ -372,10 +373,13 @@ def test_small_device_multirank(km, oracle, torch, P, transport, storage, monkey
     assert all(o is not None for o in out), "a rank did not finish"
     for c in comms:
         c.close()
-    if storage == "tiles":                             # every rank holds a share of the tiles
+    if storage == "tiles":                             # every rank holds a share of the tiles (strips of one tile: the first ranks, one each)
         nb = (out[0]["info"]["tunnel_points"] + 63) // 64
         held = [o["info"]["tunnel_bytes"] // 32768 for o in out]
-        assert sum(held) == nb * (nb + 1) // 2 and min(held) > 0, (held, nb)
+        assert sum(held) == nb * (nb + 1) // 2 and min(held[:min(P, nb * (nb + 1) // 2)]) > 0, (held, nb)
+        print("tunnel points per rank %s, tiles per rank %s" % ([o["info"]["tunnel_points_rank"] for o in out], held))
+        if P == 5:
+            assert min(o["info"]["tunnel_points_rank"] for o in out) == 0      # (the case this parameter is here for)
     xo, ito, relo = T.solve(np.zeros(T.Nsub), 1e-13, 20000)
     m = np.zeros(T.N_atom + 2)
     m[:T.Nsub] = xo * G0
@@ -391,7 +395,7 @@ def test_small_device_multirank(km, oracle, torch, P, transport, storage, monkey
         assert o["st"]["converged"] == 1 and o["st"]["iterations"] == od["iterations"], (o["st"]["iterations"], od["iterations"], ito)
         np.testing.assert_array_equal(o["v"][:T.Nsub], mo)
         assert abs(o["st"]["iterations"] - ito) <= max(3, 0.05 * ito)
-        assert o["im"] > 0 and abs(o["im"] - out[0]["im"]) == 0
+        assert (o["im"] > 0 or P == 5) and abs(o["im"] - out[0]["im"]) == 0     # (the narrowed window of the 5-rank case carries no current)
         np.testing.assert_array_equal(o["v"], out[0]["v"])             # replicated bit for bit
         np.testing.assert_array_equal(o["pw"], out[0]["pw"])
         np.testing.assert_array_equal(o["pw"] == -7.0, pw == -7.0)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--T", type=float, default=300.0)
     ap.add_argument("--max-events", type=int, default=100000)
+    ap.add_argument("--event-stats", action="store_true", help="locality of the selected rows (supertiles of 128 rows)")
     a = ap.parse_args()
     S = km.solvers
     d = km.structure.load_device_5nm("init") if a.workload == "5nm" else km.structure.synth_crossbar_40nm()
@@ -67,6 +68,24 @@ def main():
                                                       buf.site_charge, rng, layers, max_events=a.max_events,
                                                       return_log=True))
         kmc_time += ev[0]
+        if a.event_stats and ev[1] > 0:
+            # where the selection walk lands: how often a recently used supertile (128 consecutive rows of the event list)
+            # is selected again -- what a small cache of row sums in LDS would hit
+            import collections
+            st_ = ev[2][:, 0] // 128
+            line = "  events: %d, distinct supertiles %d" % (len(st_), len(set(st_.tolist())))
+            for cap in (16, 64, 256):
+                lru, hits = collections.OrderedDict(), 0
+                for q in st_.tolist():
+                    if q in lru:
+                        hits += 1
+                        lru.move_to_end(q)
+                    else:
+                        lru[q] = 1
+                        if len(lru) > cap:
+                            lru.popitem(last=False)
+                line += ", LRU-%d hit rate %.2f" % (cap, hits / len(st_))
+            print(line, flush=True)
         print("step %d: charge %.6f | boundary %.6f (%d it) | pairwise %.6f | gather %.6f | events %.6f (%d ev) | "
               "superstep %.6f | KMC time %.5e" % (step + 1, tc, tb, st["iterations"], tp, tg, te, ev[1],
                                                    tc + tb + tp + tg + te, kmc_time), flush=True)

@@ -649,7 +649,8 @@ extern "C" int kmcf_background_potential_sparse(kmcf_kstate *k, const int *d_sit
     const int max_iterations = 10000;                           // :886
     // a solve that runs as ONE resident launch (kmcf_cgr.hip) takes the right-hand side where the assembly left it and
     // the start guess / solution in the caller's array: no copy, no permuting kernel around it
-    const bool direct = m->n_loc > 0 && kmcf_pcg_resident_applies(m);
+    // (asked on EVERY rank, also one without rows: a group agrees on the resident launch through a collective the first time)
+    const bool direct = kmcf_pcg_resident_applies(m) && m->n_loc > 0;
     if (direct) { m->solve_b_src = k->d_rhs; m->solve_x_user = v_soln; }
     else {
         KMCF_HIP(hipMemcpyAsync(m->d_r, k->d_rhs, bytes, hipMemcpyDeviceToDevice, c->stream));   // internal order already

@@ -146,7 +146,8 @@ def test_conducting_crossbar_over_a_rank_group(km, monkeypatch):
     monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
     monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "60000")
     monkeypatch.delenv("KMCF_CB_SCALED", raising=False)
-    d = km.structure.synth_crossbar_40nm(tiles=4, filament=4.0)
+    cells = int(os.environ.get("KMCF_CONDUCT_TILES", "4"))            # (8: the full 40 nm crossbar, run once for profiles/r04/extras)
+    d = km.structure.synth_crossbar_40nm(tiles=cells, filament=4.0)
     N, NL = d["N"], d["N_contact"]
     N_atom = int(((d["element"] != 0) & (d["element"] != 1)).sum())
     P = 2
@@ -190,14 +191,14 @@ def test_conducting_crossbar_over_a_rank_group(km, monkeypatch):
         for c in comms:
             c.close()
         for im, il, st, info, bound in out:
-            assert st["converged"] == 1 and info["tunnel_points"] == 17722
+            assert st["converged"] == 1 and (info["tunnel_points"] == 17722 or cells != 4)
             assert info["tunnel_dense"] == (1 if name == "tiles" else 0)
             assert im == out[0][0] and abs(im - il) <= max(bound * 1.01, 1e-25) and abs(im - il) <= 1e-8 * im
         res[name] = out
-        print("  group of 2, %-6s: %d iterations, %.1f ms (%.3f ms per iteration; per rank %s GB), I_macro %.12e"
-              % (name, out[0][2]["iterations"], out[0][2]["ms_solve"], out[0][2]["ms_solve"] / out[0][2]["iterations"],
+        print("  group of 2, %-6s: %d tunnel points, %d iterations, %.1f ms (%.3f ms per iteration; per rank %s GB), I_macro %.12e"
+              % (name, out[0][3]["tunnel_points"], out[0][2]["iterations"], out[0][2]["ms_solve"], out[0][2]["ms_solve"] / out[0][2]["iterations"],
                  " / ".join("%.2f" % (o[3]["tunnel_bytes"] * 1e-9) for o in out), out[0][0]))
-    nb = (17722 + 63) // 64
+    nb = (res["tiles"][0][3]["tunnel_points"] + 63) // 64
     held = [o[3]["tunnel_bytes"] // 32768 for o in res["tiles"]]
     assert sum(held) == nb * (nb + 1) // 2 and abs(held[0] - held[1]) <= 16
     for name in res:

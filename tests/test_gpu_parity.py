@@ -356,3 +356,49 @@ def test_single_reduction_cg_variant(km, sys5, ref5, torch_cuda, oracle, residen
     assert st40["iterations"] == 40 and st40["converged"] == 0
     assert np.abs(x40.cpu().numpy() - xo).max() <= 1e-7
     np.testing.assert_allclose(st40["relres"], relo, rtol=1e-4)
+
+
+@pytest.mark.parametrize("variant", ["cg1r", "classic"])
+@pytest.mark.parametrize("tpb,g1", [(1, 8), (2, 4), (4, 2), (4, 0), (2, 0)])      # (286 tiles: one per block needs the two-hop reduction)
+def test_resident_launch_shapes_match_their_oracle(km, sys5, ref5, torch_cuda, oracle, tpb, g1, variant):
+    """The register-resident solve in the launch shapes the planner picks on OTHER sizes than the 5 nm device's default
+    (two tiles per block, flat reduction): 1 / 2 / 4 tiles per block (KMCF_CGR_TPB) and the two-hop reduction by groups of
+    g1 blocks (KMCF_CGR_G1; what a matrix of more than 1 024 tiles -- a quarter of the 40 nm crossbar -- runs), both
+    recurrences.  Each against the oracle adding along the SAME tree (plan: resident_tpb, resident_g1): identical."""
+    import os
+    torch = torch_cuda
+    S = km.solvers
+    buf, d = sys5["buf"], sys5["d"]
+    buf.site_charge.copy_(buf.site_charge.new_tensor(ref5["charge"]))
+    S.k_assemble(buf, d["Vd"], d["high_G"], d["low_G"])
+    mat = S.Distributed_matrix.from_handle(km.lib.load().kmcf_kstate_matrix(buf.K_distributed))
+    A, ks = ref5["A"], ref5["ks"]
+    env = {"KMCF_CG_VARIANT": variant, "KMCF_CG_RESIDENT": "1", "KMCF_CGR_TPB": str(tpb), "KMCF_CGR_G1": str(g1), "KMCF_CGR_CLASSIC_TILES": "100000"}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        mat.replan()                                       # (drops the cached resident plan: the next solve plans under this environment)
+        dinv = torch.as_tensor(A["dinv"], device="cuda")
+        r = torch.as_tensor(A["rhs"], device="cuda").clone()
+        x = torch.zeros_like(r)
+        st = S.conjugate_gradient_jacobi(mat, r, x, dinv, ref5["tol"], 10000)
+        r60 = torch.as_tensor(A["rhs"], device="cuda").clone()
+        x60 = torch.zeros_like(r60)
+        st60 = S.conjugate_gradient_jacobi(mat, r60, x60, dinv, ref5["tol"], 60)
+        plan = mat.sum_plan()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        mat.replan()
+    assert plan["resident_tpb"] == tpb and plan["resident_g1"] == g1, (plan["resident_tpb"], plan["resident_g1"])
+    assert st["converged"] == 1 and st["relres"] <= ref5["tol"]
+    assert_solve_bit_identical(st, x.cpu().numpy(), r.cpu().numpy(),
+                               oracle.pcg_device_order(plan, A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"], 10000, variant=variant))
+    assert st60["iterations"] == 60
+    assert_solve_bit_identical(st60, x60.cpu().numpy(), r60.cpu().numpy(),
+                               oracle.pcg_device_order(plan, A["rhs"], np.zeros(ks.n), A["dinv"], ref5["tol"], 60, variant=variant))
+    dx = np.abs(x.cpu().numpy() - ref5["x"])
+    assert dx.max() <= 5e-4 and np.median(dx) <= 5e-6

@@ -693,6 +693,7 @@ static int cgr_plan(kmcf_matrix *m)
         KMCF_HIP(hipMemcpy(&all, d_v, sizeof(double), hipMemcpyDeviceToHost));
         if (all != (double)c->nranks) pick = 0;
     }
+    if (getenv("KMCF_TRACE")) fprintf(stderr, "cgr_plan rank %d: ok %d tiles %d forced %d pick %d share %d\n", c->rank, (int)ok, m->n_sell_tiles, forced, pick, share);
     if (!pick) return KMCF_OK;
     g->tpb = pick;
     g->nblocks = (m->n_sell_tiles + pick - 1) / pick;

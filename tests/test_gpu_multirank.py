@@ -193,8 +193,8 @@ def test_p2p_transport_in_process_matches_loopback_bit_for_bit(km, oracle, dev5,
         assert a["ev_n"] == b["ev_n"] and np.array_equal(a["ev_log"], b["ev_log"]) and a["ev_t"] == b["ev_t"]
 
 
-@pytest.mark.parametrize("P", [2, 4])
-def test_resident_group_solve_matches_its_oracle_bit_for_bit(km, oracle, dev5, ref5, P, monkeypatch):
+@pytest.mark.parametrize("P,shape", [(2, None), (4, None), (2, (4, 2)), (3, (4, 4))])
+def test_resident_group_solve_matches_its_oracle_bit_for_bit(km, oracle, dev5, ref5, P, shape, monkeypatch):
     """A group's solve as ONE register-resident launch per rank (csrc/kmcf_cgr.hip with nranks > 1: the halo as
     {value, sequence} granules put straight into the receiver's window by the lane that owns the row, every rank's sums
     to a line per rank in every peer's window), P ranks = P host threads on the peer-to-peer transport: against the oracle
@@ -203,6 +203,9 @@ def test_resident_group_solve_matches_its_oracle_bit_for_bit(km, oracle, dev5, r
     the other transports."""
     monkeypatch.setenv("KMCF_CG_VARIANT", "cg1r")
     monkeypatch.setenv("KMCF_CG_RESIDENT", "1")
+    if shape:                                          # (tiles per block, blocks per reduction group: the two-hop tree inside every rank)
+        monkeypatch.setenv("KMCF_CGR_TPB", str(shape[0]))
+        monkeypatch.setenv("KMCF_CGR_G1", str(shape[1]))
     monkeypatch.delenv("KMCF_EVENTS_PARTITIONED", raising=False)
     monkeypatch.setenv("KMCF_TRANSPORT", "p2p")
     monkeypatch.setenv("KMCF_P2P_TIMEOUT_MS", "20000")
@@ -210,6 +213,10 @@ def test_resident_group_solve_matches_its_oracle_bit_for_bit(km, oracle, dev5, r
     out = _run_ranks(km, dev5, P, ref5["charge"], expect_transport="p2p (in-process group)")
     ks, A = ref5["ks"], ref5["A"]
     assert all(o["plan"]["cg_variant"] == 1 and o["plan"]["resident_tpb"] > 0 for o in out), [o["plan"]["resident_tpb"] for o in out]
+    if shape:
+        got = [(o["plan"]["resident_tpb"], o["plan"]["resident_g1"]) for o in out]
+        print("resident shapes per rank:", got)
+        assert all(g == shape for g in got), got
     counts, displs = oracle.partition(ks.n, P)
     ranks = [oracle.DeviceRank(o["plan"]) for o in out]
     rhs = np.concatenate([o["kv"]["rhs"] for o in out])

@@ -177,7 +177,11 @@ struct cgr_wait {
 };
 
 // One solve.  Block b owns tiles b TPB ... b TPB + TPB - 1 (256 threads each); blocks of one launch are all resident.
-template <int NQ, int ND, int TPB>
+// (REC: the recurrence -- 0 single-reduction, 1 the reference's; MULTI: a group of ranks.  Compile-time, so that an
+// instance carries only its own paths: the one-rank single-reduction instance with four tiles per block keeps 32 instead
+// of 124 bytes per lane in scratch under its 128-register bound and iterates 5 % faster -- 11.86 -> 11.23 us on a rank's
+// eighth of the 40 nm matrix, 6.77 -> 6.46 on the 5 nm device, same box, alternating.)
+template <int NQ, int ND, int TPB, int REC, bool MULTI>
 __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
 {
     extern __shared__ double cgr_lds[];
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                                            __builtin_amdgcn_make_buffer_rsrc(A.zll + A.zwords, 0, (int)(A.zwords * 8), 0x00020000)};
     const __amdgpu_buffer_rsrc_t srs[2] = {__builtin_amdgcn_make_buffer_rsrc(A.slot, 0, A.nblocks * 128, 0x00020000),
                                            __builtin_amdgcn_make_buffer_rsrc(A.slot + (size_t)A.nblocks * CGR_LINE, 0, A.nblocks * 128, 0x00020000)};
-    const bool multi = A.nranks > 1;
+    constexpr bool multi = MULTI;
     int put0 = 0, put1 = 0;                        // this row's entries in the put table (a row a neighbour rank needs)
     if (multi && has_row) {
         const int pr = A.put_row[row];
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     double bb = 0.0, g_old = 0.0, a_old = 0.0, rz_last = 0.0, pAp = 0.0;
     int iters = 0, done = 0;
     bool ok = true;
-    if (A.classic) {
+    if (REC == 1) {
         // ---- the reference's recurrence and operation order (:217-266; kmcf_cg.hip: cg_p_kernel, cg_xr_kernel): two
         // reduction points per iteration -- p.Ap, then r.z
         double sums[CGR_NV];
@@ -581,13 +585,24 @@ template <int NQ, int ND, int TPB>
 int cgr_run(const cgr_args &A, bool launch, hipStream_t st, cgr_launch_info *info)
 {
     const size_t lds = ((size_t)TPB * ND * CGR_W + CGR_NV * 16 + 16 + (TPB > 1 ? TPB * KMCF_BLOCK : 0)) * sizeof(double);
-    auto kern = cgr_kernel<NQ, ND, TPB>;
-    KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (info) {
+    typedef void (*kern_t)(const cgr_args);
+    // [recurrence][group of ranks]
+    const kern_t kerns[2][2] = {{cgr_kernel<NQ, ND, TPB, 0, false>, cgr_kernel<NQ, ND, TPB, 0, true>},
+                                {cgr_kernel<NQ, ND, TPB, 1, false>, cgr_kernel<NQ, ND, TPB, 1, true>}};
+    if (info) {                                    // planning: what fits whichever instance a solve will launch
         info->lds = lds;
-        KMCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info->per_cu, kern, KMCF_BLOCK * TPB, lds));
+        info->per_cu = 1 << 30;
+        for (int r = 0; r < 2; ++r)
+            for (int g = 0; g < 2; ++g) {
+                int per_cu = 0;
+                KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[r][g]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                KMCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kerns[r][g], KMCF_BLOCK * TPB, lds));
+                info->per_cu = std::min(info->per_cu, per_cu);
+            }
     }
     if (launch) {
+        const kern_t kern = kerns[A.classic == 1 ? 1 : 0][A.nranks > 1 ? 1 : 0];
+        KMCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<A.nblocks, KMCF_BLOCK * TPB, lds, st>>>(A);
         KMCF_HIP(hipGetLastError());
     }

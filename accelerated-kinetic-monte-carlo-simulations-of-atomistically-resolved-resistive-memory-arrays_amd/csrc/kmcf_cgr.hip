@@ -154,6 +154,17 @@ __device__ __forceinline__ bool ll_try16(__amdgpu_buffer_rsrc_t rs, unsigned int
     return true;
 }
 
+// ... a granule of the rank's halo zone (fine-grained window memory, written by a peer's device): the same 16-byte load
+// at system scope (sc0 sc1) through a descriptor of the zone -- one request instead of two, a 32-bit offset instead of a
+// 64-bit address per lane
+__device__ __forceinline__ bool ll_try16_sys(__amdgpu_buffer_rsrc_t rs, unsigned int byte_off, unsigned int seq, double &v)
+{
+    const cgr_u4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 17);
+    if (d.y != seq || d.w != seq) return false;
+    v = __longlong_as_double((long long)((u64)d.x | ((u64)d.z << 32)));
+    return true;
+}
+
 struct cgr_wait {
     long long t0, timeout;
     int *d_err, *h_err;
@@ -253,6 +264,10 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     const __amdgpu_buffer_rsrc_t srs[2] = {__builtin_amdgcn_make_buffer_rsrc(A.slot, 0, A.nblocks * 128, 0x00020000),
                                            __builtin_amdgcn_make_buffer_rsrc(A.slot + (size_t)A.nblocks * CGR_LINE, 0, A.nblocks * 128, 0x00020000)};
     constexpr bool multi = MULTI;
+    // (the halo zone: halo slot h, parity p at byte p * 8 halo_stride + 16 h)
+    const __amdgpu_buffer_rsrc_t hrs[2] = {
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(A.halo_ll), 0, multi ? (int)(A.halo_stride * 8) : 0, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(A.halo_ll) + (multi ? A.halo_stride : 0), 0, multi ? (int)(A.halo_stride * 8) : 0, 0x00020000)};
     int put0 = 0, put1 = 0;                        // this row's entries in the put table (a row a neighbour rank needs)
     if (multi && has_row) {
         const int pr = A.put_row[row];
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             for (int q = 0; q < CGR_WQ; ++q)
                 if (need[q]) {
                     bool got;
-                    if (multi && wc[q] >= A.n_loc) got = ll_try_sys(A.halo_ll + zpar * A.halo_stride + 2 * (size_t)(wc[q] - A.n_loc), seq, g[q]);
+                    if (multi && wc[q] >= A.n_loc) got = ll_try16_sys(zpar ? hrs[1] : hrs[0], 16u * (unsigned int)(wc[q] - A.n_loc), seq, g[q]);
                     else got = ll_try16(zb, 16u * (unsigned int)wc[q], seq, g[q]);
                     if (got) need[q] = false;
                     else all = false;

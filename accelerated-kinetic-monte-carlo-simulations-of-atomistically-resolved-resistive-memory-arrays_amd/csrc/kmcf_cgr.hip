@@ -283,7 +283,10 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         }
     };
     // y_row = sum of the row's products with version `seq` of the vector whose own entry is `own`
-    auto spmv = [&](double own) -> double {
+    // (trail: a barrier behind the row sums.  xs is written again by the NEXT product; every reduction in between -- and,
+    // with several tiles per block, the next product's own first barrier -- already orders those writes behind these reads,
+    // so only a product that is followed directly by another one in a one-tile block asks for it)
+    auto spmv = [&](double own, bool trail = false) -> double {
         const __amdgpu_buffer_rsrc_t zb = zpar ? zrs[1] : zrs[0];
         CGR_T0();
         double g[CGR_WQ];
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             }
         }
         s += dg * own;
-        __syncthreads();                                   // (xs is written again by the next product)
+        if (trail) __syncthreads();
         CGR_T(tp_row);
         return has_row ? s : 0.0;
     };
@@ -401,7 +404,9 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             CGR_T(tp_red3);
 #pragma unroll
             for (int i = 0; i < CGR_NV; ++i) out[i] = (bc[4 * i] + bc[4 * i + 1]) + (bc[4 * i + 2] + bc[4 * i + 3]);
-            __syncthreads();
+            // (bc / red are written again by the next reduction -- behind ITS first barrier, which every wavefront reaches
+            // only after these reads; a group of ranks writes bc right away, in the rank stage)
+            if (multi) __syncthreads();
             return bad == 0;
         }
         if (gw == 0 && blockIdx.x % A.g1 == 0) {           // leader of a group: one lane per block of the group
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         const int bad = __syncthreads_or(W.failed ? 1 : 0);
         CGR_T(tp_red3);
         out[0] = bc[0]; out[1] = bc[1]; out[2] = bc[2];
-        __syncthreads();                                   // (red / bc are written again by the next reduction)
+        if (multi) __syncthreads();                        // (as above)
         return bad == 0;
     };
 
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
 
     // ---- r = b - A x0 ; z = r .* dinv ; (r, z) ; b.b                          (dist_conjugate_gradient.cpp:178-213)
     publish(x);
-    const double ax = spmv(has_row ? x : 0.0);
+    const double ax = spmv(has_row ? x : 0.0, TPB == 1 && REC != 1);     // (single-reduction form: the next product follows directly)
     double r = b_i + (-1.0) * ax;
     double z = r * di;
     double gp = r * z, bbp = b_i * b_i;

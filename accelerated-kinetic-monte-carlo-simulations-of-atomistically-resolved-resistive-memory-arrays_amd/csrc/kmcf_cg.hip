@@ -841,10 +841,11 @@ static int pcg_workspace_run(kmcf_matrix *m, bool precond, double tol, int max_i
         if (precond) return pcg1_loop<true>(m, tol, max_it, fixed_iters, stats, flags);
         return pcg1_loop<false>(m, tol, max_it, fixed_iters, stats, flags);
     }
-    // the reference's recurrence as ONE register-resident launch, one rank, for SMALL matrices: with two reduction points
-    // per iteration it pays two waits for everybody's sums, which beats three kernel boundaries only while the blocks are
-    // few (us per iteration, resident / loop: 5 nm device, 286 tiles: 9.7 / 10.9; a rank's eighth of the 40 nm matrix, 881
-    // tiles: 16.3 / 14.8) -- up to 512 tiles (KMCF_CGR_CLASSIC_TILES)
+    // the reference's recurrence as ONE register-resident launch, one rank: two reduction points per iteration, i.e. two
+    // waits for everybody's sums against three kernel boundaries (us per iteration, resident / loop: 5 nm device, 286 tiles:
+    // 8.2 / 10.9-12.6; a rank's eighth of the 40 nm matrix, 881 tiles: 13.4 / 15.4 -- until the launch was specialised per
+    // recurrence, lost two barriers and learnt to delay its first polls the eighth read 16.3 / 14.8 and the limit was 512
+    // tiles) -- wherever a resident launch fits (<= 1024 tiles; KMCF_CGR_CLASSIC_TILES lowers the limit)
     if (kmcf_cgr_classic_applies(m) && (fixed_iters > 0 || max_it > 0) && kmcf_cgr_usable(m))
         return pcg_resident(m, precond, tol, max_it, fixed_iters, stats, flags, true);
     KMCF_CHECK(!m->solve_x_user && !m->solve_b_src, KMCF_ERR_STATE, "solve set up for a resident launch that does not apply");

@@ -451,10 +451,11 @@ bool kmcf_pcg_resident_applies(kmcf_matrix *m);      // kmcf_cg.hip: the next km
 int kmcf_cgr_check(kmcf_matrix *m);           // after the synchronisation: KMCF_ERR_STATE if a bounded wait expired
 int kmcf_cgr_plan_info(kmcf_matrix *m, int *tpb, int *g1, int *nblocks);
 void kmcf_cgr_free(kmcf_matrix *m);
-// the reference's recurrence runs as a resident launch only on small matrices (kmcf_cg.hip: pcg_workspace_run)
+// the reference's recurrence runs as a resident launch on one rank, wherever a resident launch fits (kmcf_cg.hip:
+// pcg_workspace_run; KMCF_CGR_CLASSIC_TILES lowers the limit)
 inline bool kmcf_cgr_classic_applies(const kmcf_matrix *m)
 {
-    static const int classic_tiles = getenv("KMCF_CGR_CLASSIC_TILES") ? atoi(getenv("KMCF_CGR_CLASSIC_TILES")) : 512;
+    static const int classic_tiles = getenv("KMCF_CGR_CLASSIC_TILES") ? atoi(getenv("KMCF_CGR_CLASSIC_TILES")) : 1024;
     return m->comm->nranks == 1 && !m->comm->force_collectives && m->n_sell_tiles <= classic_tiles;
 }
 // matrix.hip

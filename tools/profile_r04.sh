@@ -30,8 +30,8 @@ E=$OUT/extras; mkdir -p $E
 python3 $R/bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $E/bench_steps20.json
 python3 $R/bench.py --no-cpu-baseline --no-hbm-probe --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_steps300.json
 # a rank's eighth of the 40 nm matrix on one GPU: reference recurrence (3 kernels), single-reduction loop (2 kernels), resident launch
-python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_classic.json
-KMCF_CGR_CLASSIC_TILES=100000 python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_classic_resident.json
+KMCF_CG_RESIDENT=0 python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_classic.json
+python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_classic_resident.json
 KMCF_CG_VARIANT=cg1r KMCF_CG_RESIDENT=0 python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_cg1r_loop.json
 KMCF_CG_VARIANT=cg1r python3 $R/bench.py --workload small --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > $E/bench_small_cg1r_resident.json
 KMCF_CG_VARIANT=cg1r rocprofv3 --kernel-trace --stats -d $E/small_resident -o s --output-format csv -- \

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
     // (trail: a barrier behind the row sums.  xs is written again by the NEXT product; every reduction in between -- and,
     // with several tiles per block, the next product's own first barrier -- already orders those writes behind these reads,
     // so only a product that is followed directly by another one in a one-tile block asks for it)
-    int gdel = A.gather_delay, gstreak = 0, rdel = A.reduce_delay, rstreak = 0;
+    int gdel = A.gather_delay, gstreak = 0, rdel = A.reduce_delay, rstreak = 0, kdel = A.reduce_delay, kstreak = 0;
     auto spmv = [&](double own, bool trail = false) -> double {
         const __amdgpu_buffer_rsrc_t zb = zpar ? zrs[1] : zrs[0];
         CGR_T0();
@@ -502,7 +502,10 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             const u64 *src = A.red_mine + (par * P2P_MAXR + (mine ? lane : 0)) * P2P_FS;
             double g[CGR_NV] = {0.0, 0.0, 0.0};
             bool need[CGR_NV] = {mine, mine, mine && nv > 2};
+            for (int k = 0; k < kdel; ++k) __builtin_amdgcn_s_sleep(8);      // (the peers' lines: delayed and adapted like the local polls)
+            int passes = 0;
             while (true) {
+                ++passes;
                 bool all = true;
 #pragma unroll
                 for (int i = 0; i < CGR_NV; ++i)
@@ -511,6 +514,10 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                         else all = false;
                     }
                 if (all || W.give_up(14)) break;
+            }
+            if (A.adapt_delay) {
+                if (__ballot(passes > 1) != 0ull) { kdel = min(kdel + 1, 24); kstreak = 0; }
+                else if (++kstreak >= A.adapt_delay) { kdel = max(kdel - 1, 0); kstreak = 0; }
             }
             g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
             if (nv > 2) g[2] = kmcf_wave_sum64(g[2]);

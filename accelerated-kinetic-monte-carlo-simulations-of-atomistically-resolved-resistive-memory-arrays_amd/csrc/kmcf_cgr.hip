@@ -82,12 +82,13 @@ struct cgr_args {
     double tol2;
     int classic;                     // 1: the reference's recurrence (two reduction points per iteration); 0: the single-reduction form
     // A poll that comes too early costs a whole round trip (~1 us: the loop waits for its answer before asking again), so a
-    // wavefront sleeps before the FIRST poll of a gather / of a reduction's collection: units of ~0.2 us, start values
-    // (KMCF_CGR_DELAY, KMCF_CGR_RDELAY; default 3), then adapted per wavefront -- one more after a first poll that failed,
-    // one less after adapt_delay in a row that did not (KMCF_CGR_ADAPT, default 4; 0: fixed).  Measured, us per iteration,
-    // none / fixed 3 + 3 / adapted: a rank's eighth of the 40 nm matrix 11.2 / 10.5 / 10.4, the 5 nm device 6.4 / 5.8 / 5.9
-    // (longer streaks suit the eighth -- 10.2 at 16 -- and hurt the 5 nm device, 7.3: its first polls also fail for skew
-    // between blocks, which no delay cures, and the delay creeps up).
+    // wavefront sleeps before the FIRST poll of a gather / of a reduction's collection: units of ~0.1 us (s_sleep 4), start
+    // values (KMCF_CGR_DELAY, KMCF_CGR_RDELAY; default 6), then adapted per wavefront -- one more after a first poll that
+    // failed, one less after adapt_delay in a row that did not (KMCF_CGR_ADAPT, default 16; 0: fixed).  Measured, us per
+    // iteration, none / fixed / adapted: a rank's eighth of the 40 nm matrix 11.2 / 10.5 / 10.2, the 5 nm device 6.4 / 5.8 /
+    // 5.7 (with units of 0.2 us long streaks suited the eighth and hurt the 5 nm device -- 10.2 / 7.3 at 16: its first polls
+    // also fail for skew between blocks, which no delay cures, and a coarse delay creeps up; the best fixed pair per size reads
+    // 10.1 / 5.6).
     int gather_delay, reduce_delay, adapt_delay;
     int sibling_lds;                 // 1: window columns owned by a sibling tile of the block come out of LDS (KMCF_CGR_SIB=0: through the granules)
     // groups of ranks (peer-to-peer transport; kmcf_p2p_dev.hpp): nranks == 1 -> everything below unused
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
 #pragma unroll
         for (int q = 0; q < CGR_WQ; ++q) { g[q] = 0.0; need[q] = wc[q] >= 0 && !sib[q]; }
         if (TPB > 1 && has_row) zblk[row - rb0] = own;
-        for (int k = 0; k < gdel; ++k) __builtin_amdgcn_s_sleep(8);
+        for (int k = 0; k < gdel; ++k) __builtin_amdgcn_s_sleep(4);
         int passes = 0;
         while (true) {
             ++passes;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             asm volatile("" ::: "memory");                 // (the next pass loads again)
         }
         if (A.adapt_delay) {                               // (wavefront-uniform)
-            if (__ballot(passes > 1) != 0ull) { gdel = min(gdel + 1, 12); gstreak = 0; }
+            if (__ballot(passes > 1) != 0ull) { gdel = min(gdel + 1, 24); gstreak = 0; }
             else if (++gstreak >= A.adapt_delay) { gdel = max(gdel - 1, 0); gstreak = 0; }
         }
         CGR_T(tp_gather);
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
         }
         CGR_T(tp_red1);
         if (A.g1 != 0 || gw < 4)
-            for (int k = 0; k < rdel; ++k) __builtin_amdgcn_s_sleep(8);
+            for (int k = 0; k < rdel; ++k) __builtin_amdgcn_s_sleep(4);
         if (A.g1 == 0) {
             // flat (<= 256 blocks): ONE hop -- every block reads every block's line itself, lane l of wave w that of block
             // 64 w + l; a wave adds its 64 (butterfly), the four wave sums as (w0 + w1) + (w2 + w3)
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                     asm volatile("" ::: "memory");
                 }
                 if (A.adapt_delay) {
-                    if (__ballot(passes > 1) != 0ull) { rdel = min(rdel + 1, 12); rstreak = 0; }
+                    if (__ballot(passes > 1) != 0ull) { rdel = min(rdel + 1, 24); rstreak = 0; }
                     else if (++rstreak >= A.adapt_delay) { rdel = max(rdel - 1, 0); rstreak = 0; }
                 }
                 g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
             const u64 *src = A.red_mine + (par * P2P_MAXR + (mine ? lane : 0)) * P2P_FS;
             double g[CGR_NV] = {0.0, 0.0, 0.0};
             bool need[CGR_NV] = {mine, mine, mine && nv > 2};
-            for (int k = 0; k < kdel; ++k) __builtin_amdgcn_s_sleep(8);      // (the peers' lines: delayed and adapted like the local polls)
+            for (int k = 0; k < kdel; ++k) __builtin_amdgcn_s_sleep(4);      // (the peers' lines: delayed and adapted like the local polls)
             int passes = 0;
             while (true) {
                 ++passes;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(KMCF_BLOCK * TPB) void cgr_kernel(const cgr_args A)
                 if (all || W.give_up(14)) break;
             }
             if (A.adapt_delay) {
-                if (__ballot(passes > 1) != 0ull) { kdel = min(kdel + 1, 24); kstreak = 0; }
+                if (__ballot(passes > 1) != 0ull) { kdel = min(kdel + 1, 48); kstreak = 0; }
                 else if (++kstreak >= A.adapt_delay) { kdel = max(kdel - 1, 0); kstreak = 0; }
             }
             g[0] = kmcf_wave_sum64(g[0]); g[1] = kmcf_wave_sum64(g[1]);
@@ -868,9 +869,9 @@ int kmcf_cgr_solve(kmcf_matrix *m, bool precond, double tol, int max_it, int fix
     if (c->nranks > 1 && c->p2p && !getenv("KMCF_CGR_TIMEOUT_MS")) A.timeout = c->p2p->timeout_ticks;      // (a group: the transport's bound, KMCF_P2P_TIMEOUT_MS)
     A.limit = limit; A.check_tol = fixed_iters > 0 ? 0 : 1; A.tol2 = tol * tol;
     {
-        static const int gd = getenv("KMCF_CGR_DELAY") ? atoi(getenv("KMCF_CGR_DELAY")) : 3;
-        static const int rd = getenv("KMCF_CGR_RDELAY") ? atoi(getenv("KMCF_CGR_RDELAY")) : 3;
-        static const int ad = getenv("KMCF_CGR_ADAPT") ? atoi(getenv("KMCF_CGR_ADAPT")) : 4;
+        static const int gd = getenv("KMCF_CGR_DELAY") ? atoi(getenv("KMCF_CGR_DELAY")) : 6;
+        static const int rd = getenv("KMCF_CGR_RDELAY") ? atoi(getenv("KMCF_CGR_RDELAY")) : 6;
+        static const int ad = getenv("KMCF_CGR_ADAPT") ? atoi(getenv("KMCF_CGR_ADAPT")) : 16;
         A.gather_delay = gd; A.reduce_delay = rd; A.adapt_delay = ad;
     }
     A.classic = classic ? 1 : 0;
